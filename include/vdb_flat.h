@@ -1,0 +1,159 @@
+/*
+ * vdb_flat.h -- C ABI of the MI355X-native brute-force kNN engine.
+ *
+ * This is the drop-in boundary for the reference's FlatIndex hot path
+ * (Ricoledan/vectordb-from-scratch).  The reference has no FFI layer; its seam
+ * is the Rust trait `Index` (src/index.rs:11-35) implemented by `FlatIndex`
+ * (src/flat_index.rs:37-74) and consumed by `VectorStore<I: Index>`
+ * (src/storage.rs:83, :116-127).  Every entry point below names the reference
+ * interface it replaces.  The Rust binding a maintainer would add is in
+ * INTEGRATION.md; a C++ mirror of the trait lives in
+ * vectordb-from-scratch_amd/host/.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++ / torch types cross this boundary;
+ *  - every function returns a vdb_status (0 = ok); no exception or panic
+ *    crosses the boundary; vdb_last_error() gives the message and, for a
+ *    dimension mismatch, the expected/actual pair (src/error.rs:12-13);
+ *  - inputs are borrowed for the duration of the call; outputs are
+ *    caller-allocated;
+ *  - ids are the reference's `usize` internal ids, passed as uint64_t;
+ *  - vectors are row-major little-endian f32, the byte layout of
+ *    src/persistence/mmap.rs:77-84;
+ *  - search entry points may be called concurrently from several threads on
+ *    one handle (the server holds RwLock::read() around search,
+ *    src/server/routes.rs:244,:342); add/remove are externally serialised by
+ *    the caller's write lock (routes.rs:141,:210,:300).
+ */
+#ifndef VDB_FLAT_H
+#define VDB_FLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* src/distance.rs:9-16  enum DistanceMetric */
+typedef enum vdb_metric {
+    VDB_METRIC_EUCLIDEAN = 0, /* sqrt(sum (a-b)^2)              distance.rs:37-44 */
+    VDB_METRIC_COSINE = 1,    /* 1 - clamp(dot/(|a||b|), -1, 1) distance.rs:47-64 */
+    VDB_METRIC_DOT = 2        /* -dot(a, b)                     distance.rs:31,:67-73 */
+} vdb_metric;
+
+/* src/error.rs:10-31  enum VectorDbError, as integer codes */
+typedef enum vdb_status {
+    VDB_OK = 0,
+    VDB_ERR_DIMENSION_MISMATCH = 1, /* error.rs:12  DimensionMismatch{expected,actual} */
+    VDB_ERR_INVALID_VECTOR = 2,     /* error.rs:18  InvalidVector (zero norm under Cosine, distance.rs:51-55) */
+    VDB_ERR_NAN = 3,                /* the reference panics on a NaN distance (flat_index.rs:62); a panic cannot cross a C ABI */
+    VDB_ERR_DEVICE = 4,             /* HIP runtime failure -> error.rs:30 IndexError(String) */
+    VDB_ERR_INVALID_ARGUMENT = 5,   /* null pointer, bad metric, ... -> IndexError(String) */
+    VDB_ERR_NOT_FOUND = 6           /* get_vector on an absent id (index.rs:23 returns None) */
+} vdb_status;
+
+typedef struct vdb_flat_index vdb_flat_index; /* opaque; owns all device and staging memory */
+
+/* FlatIndex::new(metric)  src/flat_index.rs:19-25.  `device` is the HIP device ordinal. */
+int vdb_flat_create(int metric, int device, vdb_flat_index **out);
+void vdb_flat_destroy(vdb_flat_index *h);
+
+/* Index::add(id, vector)  src/index.rs:13, src/flat_index.rs:38-41.
+ * Copies the row.  An existing id is overwritten silently (HashMap::insert).
+ * Like the reference there is NO dimension check at add: a row whose dimension
+ * differs from the rows already stored is kept (host side) and makes later
+ * searches fail with DimensionMismatch, exactly as distance.rs:21-26 does. */
+int vdb_flat_add(vdb_flat_index *h, uint64_t id, const float *vector, size_t dim);
+
+/* N adds in one call (what 1M calls of Index::add amount to, storage.rs:135-172).
+ * rows is [n][dim] contiguous; ids[i] belongs to row i (ids == NULL: first_id + i). */
+int vdb_flat_add_bulk(vdb_flat_index *h, const uint64_t *ids, uint64_t first_id, const float *rows,
+                      size_t n, size_t dim);
+/* Same, with `d_rows` already resident in this device's HBM (device-to-device copy). */
+int vdb_flat_add_bulk_device(vdb_flat_index *h, const uint64_t *ids, uint64_t first_id,
+                             const float *d_rows, size_t n, size_t dim);
+
+/* Index::remove(id)  src/index.rs:16, src/flat_index.rs:43-46.  Absent id is VDB_OK. */
+int vdb_flat_remove(vdb_flat_index *h, uint64_t id);
+
+/* Index::get_vector(id)  src/index.rs:23.  Copies up to cap floats into out, sets *dim. */
+int vdb_flat_get_vector(vdb_flat_index *h, uint64_t id, float *out, size_t cap, size_t *dim);
+
+/* Index::len / Index::metric  src/index.rs:26-29.  vdb_flat_dim: dimension of the stored rows (0 if empty). */
+size_t vdb_flat_len(const vdb_flat_index *h);
+int vdb_flat_metric(const vdb_flat_index *h);
+size_t vdb_flat_dim(const vdb_flat_index *h);
+
+/* Pre-size the device row store (optional; avoids regrowth copies during a bulk build). */
+int vdb_flat_reserve(vdb_flat_index *h, size_t rows, size_t dim);
+
+/* Push staged adds/removes to the device now (otherwise done lazily by the next search). */
+int vdb_flat_flush(vdb_flat_index *h);
+
+/* Index::search(query, k)  src/index.rs:20, src/flat_index.rs:52-65.
+ * out_ids/out_dists hold k entries; *out_count = min(k, len).  Ascending by
+ * (distance, id): the reference's tie order is HashMap-random. */
+int vdb_flat_search(vdb_flat_index *h, const float *query, size_t dim, size_t k, uint64_t *out_ids,
+                    float *out_dists, size_t *out_count);
+
+/*
+ * The batched hot call.  Replaces the sequential loop of
+ * VectorStore::search_batch (src/storage.rs:302-310) over FlatIndex::search,
+ * with the per-query k of `&[(Vector, usize)]` (storage.rs:304).
+ *   queries   [nq][dim] row-major f32 (host memory)
+ *   ks        per-query k, or NULL to use `k` for every query
+ *   id_mask   optional pre-filter: bit i (LSB-first in 64-bit words) set = id i
+ *             eligible; ids >= mask_bits are not eligible; NULL = no filter.
+ *             (BASELINE config 4; the reference post-filters a 3x over-fetch,
+ *             storage.rs:249-290, whose result is a prefix of this one.)
+ *   out_ids / out_dists   [nq][kstride], caller-allocated, kstride >= max k
+ *   out_counts            [nq]: min(k_b, eligible rows)
+ * The first failing query fails the whole batch (storage.rs:309).
+ */
+int vdb_flat_search_batch(vdb_flat_index *h, const float *queries, size_t nq, size_t dim,
+                          const size_t *ks, size_t k, const uint64_t *id_mask, size_t mask_bits,
+                          size_t kstride, uint64_t *out_ids, float *out_dists, size_t *out_counts);
+
+/*
+ * Same call with queries and outputs resident in this device's HBM and one k
+ * for the whole batch; `stream` is a hipStream_t (NULL = the handle's own
+ * stream).  d_id_mask is a device pointer (or NULL).  The call returns after
+ * the results are complete on `stream` (it synchronises that stream once to
+ * read the status word).  d_out_counts is uint32_t[nq].
+ */
+int vdb_flat_search_batch_device(vdb_flat_index *h, const float *d_queries, size_t nq, size_t dim,
+                                 size_t k, const uint64_t *d_id_mask, size_t mask_bits,
+                                 uint64_t *d_out_ids, float *d_out_dists, uint32_t *d_out_counts,
+                                 void *stream);
+
+/*
+ * Multi-GPU exchange step: merge `nparts` partial top-k lists per query
+ * (gathered from the row shards with an RCCL all-gather) into the global
+ * top-k, ascending by (distance, id).  All pointers are device pointers on
+ * `device`; parts are laid out [nparts][nq][k] with counts [nparts][nq].
+ */
+int vdb_merge_topk_device(int device, const uint64_t *d_part_ids, const float *d_part_dists,
+                          const uint32_t *d_part_counts, size_t nparts, size_t nq, size_t k,
+                          uint64_t *d_out_ids, float *d_out_dists, uint32_t *d_out_counts,
+                          void *stream);
+
+/* Counters of the last search on this handle (diagnostics, tests, bench):
+ *  [0] queries answered by the MFMA path   [1] queries re-done by the exact-scan fallback
+ *  [2] candidate-pool overflows            [3] rows scanned by the fused kernel
+ *  [4] sample rows used for the thresholds [5] k' (candidates kept per query)
+ *  [6] uncertified queries                 [7] reserved */
+int vdb_flat_last_stats(const vdb_flat_index *h, uint64_t out[8]);
+
+/* Thread-local message of the last failing call on this thread, plus the
+ * DimensionMismatch pair (error.rs:12-13).  Any pointer may be NULL. */
+void vdb_last_error(char *buf, size_t cap, size_t *expected, size_t *actual);
+
+/* Library/ABI version and the GPU architecture the kernels were built for ("gfx950"). */
+int vdb_abi_version(void);
+const char *vdb_build_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDB_FLAT_H */

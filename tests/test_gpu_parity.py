@@ -1,0 +1,287 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle.  Integer results (ids, counts,
+order) must match exactly; distances are recomputed on the GPU in the reference's operation order
+and must be BIT-IDENTICAL to the oracle's (tolerance 0)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import load_package
+
+pytestmark = pytest.mark.gpu
+
+M = {"euclidean": 0, "cosine": 1, "dot": 2}
+
+
+@pytest.fixture(scope="module")
+def vdb():
+    v = load_package()
+    v.build()
+    return v
+
+
+def make_index(vdb, metric, rows, ids=None):
+    ix = vdb.GpuFlatIndex(vdb.DistanceMetric(metric), keep_host_copy=False)
+    ix.add_bulk(rows, ids=ids)
+    return ix
+
+
+def check_against_oracle(vdb, metric, rows, queries, k, ids=None, live=None, ix=None, qsel=None):
+    ix = ix or make_index(vdb, metric, rows, ids)
+    gi, gd, gc = ix.search_batch_arrays(queries, k)
+    qsel = range(queries.shape[0]) if qsel is None else qsel
+    for b in qsel:
+        oi, od = oracle.flat_search(metric, rows, queries[b], k, ids=ids, live=live)
+        assert gc[b] == len(oi), (b, gc[b], len(oi))
+        assert np.array_equal(gi[b, :gc[b]], oi), (b, gi[b, :gc[b]], oi, gd[b, :gc[b]], od)
+        assert np.array_equal(gd[b, :gc[b]].view(np.uint32), od.view(np.uint32)), (b, gd[b, :gc[b]], od)
+    return ix
+
+
+# ------------------------------------------------------------------ reference known answers
+def test_known_flat_search(vdb, known_answers):
+    for c in known_answers["flat_search"]:
+        ix = vdb.GpuFlatIndex(vdb.DistanceMetric(M[c["metric"]]))
+        for i, v in c["rows"].items():
+            ix.add(int(i), vdb.Vector(v))
+        res = ix.search(vdb.Vector(c["query"]), c["k"])
+        assert len(res) == c["expect_len"], c["src"]
+        assert res[0][0] == c["expect_first_id"], c["src"]
+        if "expect_first_dist_lt" in c:
+            assert res[0][1] < c["expect_first_dist_lt"]
+
+
+def test_known_distances_via_single_row_index(vdb, known_answers):
+    for c in known_answers["distance"]:
+        metric = "dot" if c["metric"] == "dot_raw" else c["metric"]
+        ix = vdb.GpuFlatIndex(vdb.DistanceMetric(M[metric]))
+        ix.add(0, vdb.Vector(c["b"]))
+        (rid, d), = ix.search(vdb.Vector(c["a"]), 1)
+        d = -d if c["metric"] == "dot_raw" else d
+        assert abs(float(d) - c["expect"]) <= c["eps"] * max(1.0, abs(c["expect"])), c["src"]
+        assert float(d) == float((-1 if c["metric"] == "dot_raw" else 1) * oracle.distance(M[metric], c["a"], c["b"]))
+
+
+def test_known_store_cases(vdb, known_answers):
+    V, S = vdb.Vector, vdb.VectorStore
+    for c in known_answers["empty_store"]:
+        assert S(M[c["metric"]]).search(V(c["query"]), c["k"]) == []
+    for c in known_answers["remove"]:
+        ix = vdb.GpuFlatIndex(vdb.DistanceMetric(M[c["metric"]]))
+        for i, v in c["rows"].items():
+            ix.add(int(i), V(v))
+        assert ix.len() == c["expect_len_before"]
+        for i in c["remove"]:
+            ix.remove(i)
+        assert ix.len() == c["expect_len_after"]
+    for c in known_answers["filter"]:
+        st = S(M[c["metric"]])
+        for name, v in c["rows"].items():
+            st.insert_with_metadata(name, V(v), vdb.Metadata(c["meta"][name]))
+        f = vdb.MetadataFilter.Eq(c["filter"]["field"], c["filter"]["value"])
+        got = st.search_with_filter(V(c["query"]), c["k"], f)
+        assert sorted(r.id for r in got) == sorted(c["expect_id_set"]), c["src"]
+        pre = st.search_batch_prefiltered([(V(c["query"]), c["k"])], f)[0]
+        assert [r.id for r in pre][:len(got)] == [r.id for r in got]      # reference result is a prefix
+    for c in known_answers["batch"]:
+        st = S(M[c["metric"]])
+        for name, v in c["rows"].items():
+            st.insert(name, V(v))
+        res = st.search_batch([(V(q), k) for q, k in c["queries"]])
+        assert [[r.id for r in rs] for rs in res] == c["expect_ids"]
+    for c in known_answers["batch_filter"]:
+        st = S(M[c["metric"]])
+        for name, v in c["rows"].items():
+            st.insert_with_metadata(name, V(v), vdb.Metadata(c["meta"][name]))
+        f = vdb.MetadataFilter.Eq(c["filter"]["field"], c["filter"]["value"])
+        res = st.search_batch_with_filter([(V(q), k) for q, k in c["queries"]], f)
+        assert [[r.id for r in rs] for rs in res] == c["expect_ids"]
+    for c in known_answers["insert_errors"]:
+        st = S(0)
+        st.insert("v1", V(c["first"]))
+        with pytest.raises(vdb.DimensionMismatch):
+            st.insert("v2", V(c["second"]))
+
+
+# ------------------------------------------------------------------ committed golden vectors
+def test_golden_vectors(vdb, golden_cases):
+    g = golden_cases
+    for name in sorted({k.split("/")[0] for k in g.files}):
+        rows, queries, ids = g[f"{name}/rows"], g[f"{name}/queries"], g[f"{name}/ids"]
+        for mname, m in M.items():
+            ix = None
+            for k in g[f"{name}/ks"]:
+                key = f"{name}/{mname}/k{k}/ids"
+                if key not in g.files:
+                    continue
+                ix = ix or make_index(vdb, m, rows, ids)
+                gi, gd, gc = ix.search_batch_arrays(queries, int(k))
+                eid, ed = g[key], g[f"{name}/{mname}/k{k}/dists"]
+                assert np.all(gc == eid.shape[1]), (name, mname, k)
+                assert np.array_equal(gi[:, :eid.shape[1]], eid), (name, mname, k)
+                assert np.array_equal(gd[:, :eid.shape[1]].view(np.uint32), ed.view(np.uint32)), (name, mname, k)
+
+
+# ------------------------------------------------------------------ seeded sweeps vs the oracle
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("n,d,nq,k", [(1, 3, 1, 1), (31, 5, 3, 4), (1000, 33, 17, 10), (5000, 128, 40, 10)])
+def test_small_index_paths(vdb, metric, n, d, nq, k):
+    rng = np.random.default_rng(n * 7 + d)
+    rows = rng.random((n, d), dtype=np.float32)
+    q = rng.random((nq, d), dtype=np.float32)
+    check_against_oracle(vdb, metric, rows, q, k)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("n,d,nq,k", [(20000, 64, 33, 10), (50000, 128, 70, 10), (40000, 50, 130, 25),
+                                      (70001, 96, 256, 10), (30000, 32, 5, 100)])
+def test_fused_path_vs_oracle(vdb, metric, n, d, nq, k):
+    rng = np.random.default_rng(n + d + nq)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    ix = check_against_oracle(vdb, metric, rows, q, k, qsel=range(0, nq, max(1, nq // 12)))
+    st = ix.last_stats()
+    assert st["rows_scanned"] >= n and st["sample_rows"] > 0, st      # the fused MFMA kernel ran
+    assert st["pool_overflows"] == 0, st
+
+
+def test_uniform_concentrated_data(vdb):
+    # the reference benches' distribution: uniform[0,1) (benches/search_bench.rs:6-13)
+    rng = np.random.default_rng(5)
+    rows = rng.random((120000, 128), dtype=np.float32)
+    q = rng.random((64, 128), dtype=np.float32)
+    q[0] = 0.5                                                         # the bench query [0.5; 128]
+    for metric in (0, 1, 2):
+        ix = check_against_oracle(vdb, metric, rows, q, 10, qsel=range(0, 64, 8))
+        st = ix.last_stats()
+        assert st["exact_queries"] == 0, st                            # every query certified on the MFMA path
+
+
+def test_forced_exact_fallback_matches(vdb):
+    rng = np.random.default_rng(11)
+    rows = rng.standard_normal((30000, 40)).astype(np.float32)
+    q = rng.standard_normal((9, 40)).astype(np.float32)
+    ix = make_index(vdb, 0, rows)
+    a = ix.search_batch_arrays(q, 10)
+    os.environ["VDB_FORCE_EXACT"] = "1"
+    try:
+        b = ix.search_batch_arrays(q, 10)
+        assert ix.last_stats()["exact_queries"] == 9
+    finally:
+        del os.environ["VDB_FORCE_EXACT"]
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    check_against_oracle(vdb, 0, rows, q, 10, ix=ix)
+
+
+def test_large_k_uses_exact_path(vdb):
+    rng = np.random.default_rng(12)
+    rows = rng.random((3000, 24), dtype=np.float32)
+    q = rng.random((4, 24), dtype=np.float32)
+    for metric in (0, 1, 2):
+        check_against_oracle(vdb, metric, rows, q, 500)
+        check_against_oracle(vdb, metric, rows, q, 5000)               # k > n returns n results
+
+
+def test_duplicates_and_near_ties_are_certified_or_fall_back(vdb):
+    rng = np.random.default_rng(13)
+    base = rng.random((500, 48), dtype=np.float32)
+    rows = np.concatenate([base] * 80, 0)                              # 40000 rows, every row 80 times
+    ids = rng.permutation(rows.shape[0]).astype(np.uint64)             # ids not monotone in row order
+    q = base[:6] + 0.0
+    for metric in (0, 1, 2):
+        check_against_oracle(vdb, metric, rows, q, 10, ids=ids)
+
+
+# ------------------------------------------------------------------ mutation semantics
+def test_remove_overwrite_and_tombstones(vdb):
+    rng = np.random.default_rng(14)
+    n, d = 26000, 20
+    rows = rng.random((n, d), dtype=np.float32)
+    q = rng.random((7, d), dtype=np.float32)
+    ix = make_index(vdb, 0, rows)
+    live = np.ones(n, dtype=np.uint8)
+    for r in rng.choice(n, 3000, replace=False):
+        ix.remove(int(r))
+        live[r] = 0
+    ix.remove(10 ** 9)                                                 # absent id is Ok (flat_index.rs:43-46)
+    assert ix.len() == int(live.sum())
+    check_against_oracle(vdb, 0, rows, q, 10, live=live, ix=ix)
+    # overwrite an id with new data (HashMap::insert, flat_index.rs:39)
+    rows2 = rows.copy()
+    for r in (5, 77, 4000):
+        rows2[r] = q[0] + 1e-3 * (r % 7)
+        ix.add(r, vdb.Vector(rows2[r]))
+        live[r] = 1
+    assert ix.len() == int(live.sum())
+    check_against_oracle(vdb, 0, rows2, q, 10, live=live, ix=ix)
+
+
+def test_prefilter_mask_matches_oracle_and_reference_prefix(vdb):
+    rng = np.random.default_rng(15)
+    n, d, k = 40000, 32, 10
+    rows = rng.random((n, d), dtype=np.float32)
+    q = rng.random((5, d), dtype=np.float32)
+    ix = make_index(vdb, 0, rows)
+    keep = (np.arange(n) % 4 == 0)                                     # 25% selectivity
+    mask = np.zeros((n + 63) // 64, dtype=np.uint64)
+    for i in np.nonzero(keep)[0]:
+        mask[i >> 6] |= np.uint64(1) << np.uint64(i & 63)
+    gi, gd, gc = ix.search_batch_arrays(q, k, id_mask=mask, mask_bits=n)
+    for b in range(5):
+        oi, od = oracle.flat_search(0, rows, q[b], k, live=keep.astype(np.uint8))
+        assert np.array_equal(gi[b, :gc[b]], oi) and np.array_equal(gd[b, :gc[b]], od)
+        ri, rd = oracle.search_with_filter(0, rows, q[b], k, keep.astype(np.uint8))   # reference post-filter
+        assert np.array_equal(gi[b, :len(ri)], ri)                     # ... is a prefix of the pre-filter
+
+
+# ------------------------------------------------------------------ error semantics
+def test_error_semantics(vdb):
+    V = vdb.Vector
+    ix = vdb.GpuFlatIndex(vdb.DistanceMetric.Cosine)
+    ix.add(0, V([1, 0, 0]))
+    ix.add(1, V([0, 0, 0]))                                            # zero row is accepted at add ...
+    with pytest.raises(vdb.InvalidVector):                             # ... and fails every search
+        ix.search(V([1, 1, 0]), 1)
+    ix.remove(1)
+    assert ix.search(V([1, 1, 0]), 1)[0][0] == 0
+    with pytest.raises(vdb.InvalidVector):
+        ix.search(V([0, 0, 0]), 1)                                     # zero query
+    with pytest.raises(vdb.DimensionMismatch) as e:
+        ix.search(V([1, 0]), 1)
+    assert (e.value.expected, e.value.actual) == (2, 3)                # distance.rs:22-25
+    ix.add(5, V([1, 2]))                                               # no dimension check at add (flat_index.rs:38)
+    with pytest.raises(vdb.DimensionMismatch):
+        ix.search(V([1, 0, 0]), 1)
+    ix.remove(5)
+    assert len(ix.search(V([1, 0, 0]), 3)) == 1
+    e2 = vdb.GpuFlatIndex(vdb.DistanceMetric.Euclidean)
+    assert e2.search(V([1, 2, 3]), 5) == []                            # empty index
+    e2.add(0, V([float("nan"), 1.0]))
+    e2.add(1, V([0.0, 1.0]))
+    with pytest.raises(vdb.NanDistance):                               # reference panics (flat_index.rs:62)
+        e2.search(V([0.0, 0.0]), 1)
+    assert e2.search(V([1.0, 1.0]), 0) == []
+
+
+def test_per_query_k_and_ragged_batch(vdb):
+    rng = np.random.default_rng(16)
+    rows = rng.random((900, 12), dtype=np.float32)
+    ix = make_index(vdb, 2, rows)
+    q = rng.random((6, 12), dtype=np.float32)
+    ks = np.array([1, 10, 0, 3, 950, 7])
+    gi, gd, gc = ix.search_batch_arrays(q, ks)
+    for b in range(6):
+        oi, od = oracle.flat_search(2, rows, q[b], int(ks[b]))
+        assert gc[b] == len(oi) and np.array_equal(gi[b, :gc[b]], oi) and np.array_equal(gd[b, :gc[b]], od)
+
+
+def test_recall_is_one(vdb):
+    rng = np.random.default_rng(17)
+    rows = rng.random((60000, 64), dtype=np.float32)
+    q = rng.random((32, 64), dtype=np.float32)
+    ix = make_index(vdb, 1, rows)
+    gi, _, gc = ix.search_batch_arrays(q, 10)
+    rec = [oracle.recall(oracle.flat_search(1, rows, q[b], 10)[0], gi[b, :gc[b]]) for b in range(0, 32, 4)]
+    assert min(rec) == 1.0

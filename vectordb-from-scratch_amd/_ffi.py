@@ -1,0 +1,67 @@
+"""ctypes binding of include/vdb_flat.h.  There is no CPU path: if libvdbflat.so is missing
+or no MI355X is visible, creating an index raises."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libvdbflat.so")
+
+OK, ERR_DIMENSION_MISMATCH, ERR_INVALID_VECTOR, ERR_NAN, ERR_DEVICE, ERR_INVALID_ARGUMENT, ERR_NOT_FOUND = range(7)
+
+# every symbol include/vdb_flat.h declares
+SYMBOLS = [
+    "vdb_flat_create", "vdb_flat_destroy", "vdb_flat_add", "vdb_flat_add_bulk", "vdb_flat_add_bulk_device",
+    "vdb_flat_remove", "vdb_flat_get_vector", "vdb_flat_len", "vdb_flat_metric", "vdb_flat_dim",
+    "vdb_flat_reserve", "vdb_flat_flush", "vdb_flat_search", "vdb_flat_search_batch",
+    "vdb_flat_search_batch_device", "vdb_merge_topk_device", "vdb_flat_last_stats", "vdb_last_error",
+    "vdb_abi_version", "vdb_build_arch",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -m vectordb-from-scratch_amd/build.py "
+            "or __graft_entry__.build()); this engine has no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    vp, sz, u64 = c.c_void_p, c.c_size_t, c.c_uint64
+    fp, u64p, szp, u32p = c.POINTER(c.c_float), c.POINTER(c.c_uint64), c.POINTER(c.c_size_t), c.POINTER(c.c_uint32)
+    L.vdb_flat_create.argtypes = [c.c_int, c.c_int, c.POINTER(vp)]
+    L.vdb_flat_destroy.argtypes = [vp]
+    L.vdb_flat_destroy.restype = None
+    L.vdb_flat_add.argtypes = [vp, u64, fp, sz]
+    L.vdb_flat_add_bulk.argtypes = [vp, u64p, u64, fp, sz, sz]
+    L.vdb_flat_add_bulk_device.argtypes = [vp, u64p, u64, vp, sz, sz]
+    L.vdb_flat_remove.argtypes = [vp, u64]
+    L.vdb_flat_get_vector.argtypes = [vp, u64, fp, sz, szp]
+    L.vdb_flat_len.argtypes = [vp]
+    L.vdb_flat_len.restype = sz
+    L.vdb_flat_metric.argtypes = [vp]
+    L.vdb_flat_dim.argtypes = [vp]
+    L.vdb_flat_dim.restype = sz
+    L.vdb_flat_reserve.argtypes = [vp, sz, sz]
+    L.vdb_flat_flush.argtypes = [vp]
+    L.vdb_flat_search.argtypes = [vp, fp, sz, sz, u64p, fp, szp]
+    L.vdb_flat_search_batch.argtypes = [vp, fp, sz, sz, szp, sz, u64p, sz, sz, u64p, fp, szp]
+    L.vdb_flat_search_batch_device.argtypes = [vp, vp, sz, sz, sz, vp, sz, vp, vp, vp, vp]
+    L.vdb_merge_topk_device.argtypes = [c.c_int, vp, vp, vp, sz, sz, sz, vp, vp, vp, vp]
+    L.vdb_flat_last_stats.argtypes = [vp, u64p]
+    L.vdb_last_error.argtypes = [c.c_char_p, sz, szp, szp]
+    L.vdb_last_error.restype = None
+    L.vdb_abi_version.restype = c.c_int
+    L.vdb_build_arch.restype = c.c_char_p
+    _lib = L
+    return L
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    e, a = ctypes.c_size_t(), ctypes.c_size_t()
+    lib().vdb_last_error(buf, 512, ctypes.byref(e), ctypes.byref(a))
+    return buf.value.decode("utf-8", "replace"), e.value, a.value

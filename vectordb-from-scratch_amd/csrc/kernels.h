@@ -1,0 +1,158 @@
+// kernels.h -- parameter blocks and launchers shared by the HIP translation units
+// and the host-side index (vdb_flat.cpp).  gfx950 (MI355X) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace vdb {
+
+enum Metric : int { EUCLID = 0, COSINE = 1, DOT = 2 };
+
+// Status bits written by kernels into the per-search status word.
+enum : uint32_t {
+    ST_NAN = 1u,          // a NaN distance was produced (reference: panic, flat_index.rs:62)
+    ST_ZERO_QUERY = 2u,   // zero-norm query under Cosine (distance.rs:51-55)
+};
+
+constexpr uint64_t EMPTY_KEY = ~0ull;   // pool / candidate slot that holds no row
+constexpr int KSTAGE = 32;              // K elements per LDS stage; device row stride is a multiple of it
+
+// Order-preserving map f32 -> u32 (ascending unsigned == ascending float; -0 < +0).
+__host__ __device__ inline uint32_t f32_to_ordered(float f) {
+#ifdef __HIP_DEVICE_COMPILE__
+    uint32_t b = __float_as_uint(f);
+#else
+    union { float f; uint32_t u; } c; c.f = f; uint32_t b = c.u;
+#endif
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ inline float ordered_to_f32(uint32_t k) {
+    uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(b);
+#else
+    union { float f; uint32_t u; } c; c.u = b; return c.f;
+#endif
+}
+// Candidate key: ranking score in the high word, device row (or id rank) in the low word.
+// A NaN score gets the smallest key so that it is always selected and reported.
+__host__ __device__ inline uint64_t make_key(float score, uint32_t row) {
+    uint32_t hi = (score != score) ? 0u : f32_to_ordered(score);
+    return ((uint64_t)hi << 32) | row;
+}
+
+// ---------------------------------------------------------------- row store statistics
+struct RowStatsParams {
+    const float* rows; uint32_t ld; uint32_t dim;
+    uint32_t row_begin, row_end;
+    int metric;
+    float* nd;        // exact-order norm  sqrt(fold(x*x))      (vector.rs:35-37)
+    float* alpha;     // score = fma(dot, alpha, beta)
+    float* beta;
+    uint32_t* nd2max_bits;   // atomicMax of the f32 bits of fold(x*x)
+};
+void launch_row_stats(const RowStatsParams& p, hipStream_t s);
+
+// count live rows whose norm is exactly zero (Cosine: distance.rs:51-55)
+void launch_count_zero_live(const float* nd, const uint32_t* livemask, uint32_t n_rows,
+                            uint32_t* out_count, hipStream_t s);
+
+// rowmask[w] = live[w] & (id mask bits gathered through row_ids)
+void launch_build_rowmask(const uint64_t* row_ids, const uint32_t* livemask, const uint64_t* idmask,
+                          uint64_t mask_bits, uint32_t n_rows, uint32_t* out_mask, hipStream_t s);
+
+// ---------------------------------------------------------------- query preparation
+struct QueryPrepParams {
+    const float* q_in; uint32_t dim; uint32_t nq;      // [nq][dim] as handed over
+    float* qp; uint32_t ld; uint32_t nq_pad;           // [nq_pad][ld], zero padded
+    float* qnorm;                                      // exact-order norm per query [nq_pad]
+    float* thr;                                        // padding queries get -inf here (nothing passes)
+    int metric;
+    uint32_t* status;
+};
+void launch_query_prep(const QueryPrepParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------- dense scores (sample / small N)
+struct DenseParams {
+    const float* rows; uint32_t ld; uint32_t n_rows;
+    const float* qp; uint32_t nq_pad;                  // multiple of 32
+    const float* alpha; const float* beta;
+    const uint32_t* rowmask;                           // may be null (all rows eligible)
+    uint32_t n_sample;                                 // sample j -> row j*n_rows/n_sample
+    uint64_t* keys; uint32_t key_stride;               // keys[q*key_stride + j]
+};
+void launch_dense_scores(const DenseParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------- per-query radix select
+struct SelectParams {
+    const uint64_t* keys; size_t stride;               // per-query key block
+    const uint32_t* counts; uint32_t n_fixed;          // counts != null: n = min(counts[q], cap)
+    uint32_t cap;
+    uint32_t kk;                                       // how many smallest keys to keep (<= 2048)
+    uint64_t* out_keys; uint32_t out_stride;           // sorted ascending, padded with EMPTY_KEY
+    uint32_t* out_cnt;
+    float* out_thr;                                    // may be null: score of the kk-th key, +inf if fewer
+    uint32_t* ovf;                                     // may be null: set when counts[q] > cap
+};
+void launch_select(const SelectParams& p, uint32_t nq, hipStream_t s);
+
+// ---------------------------------------------------------------- fused MFMA score + threshold filter
+struct FusedParams {
+    const float* rows; uint32_t ld; uint32_t n_rows;
+    const float* qp;                                   // padded queries, row q_base is the first of this launch
+    uint32_t q_base;
+    const float* alpha; const float* beta;
+    const uint32_t* rowmask;                           // may be null
+    const float* thr;                                  // [nq_pad] inclusive threshold per query
+    uint64_t* pool; uint32_t* pool_cnt; uint32_t capq; // pool[q*capq + slot]
+    uint32_t n_wg;                                     // row ranges = grid.x
+};
+// nqt = number of 32-query tiles handled per workgroup (1, 2, 4 or 8); grid.y super-tiles of 32*nqt queries
+void launch_fused(const FusedParams& p, int nqt, uint32_t n_super, hipStream_t s);
+size_t fused_lds_bytes(int nqt);
+uint32_t fused_tile_rows(int nqt);
+
+// ---------------------------------------------------------------- exact re-rank + certification
+struct RerankParams {
+    const float* rows; uint32_t ld; uint32_t dim; uint32_t n_rows;
+    const float* qp; const float* qnorm;
+    const float* nd;
+    const uint64_t* row_ids;
+    const uint32_t* rowmask;                           // may be null
+    const uint64_t* cand; uint32_t cand_stride; const uint32_t* cand_cnt; uint32_t kp;
+    int metric;
+    uint32_t k;                                        // results wanted per query
+    float eps_coef; const uint32_t* nd2max_bits;       // certification bound inputs (max row norm^2, f32 bits)
+    uint64_t* out_ids; float* out_dists; uint32_t* out_counts; uint32_t out_stride;
+    uint32_t* cert;                                    // [nq]: 1 = certified exact
+    uint32_t* status;
+};
+void launch_rerank(const RerankParams& p, uint32_t nq, hipStream_t s);
+
+// ---------------------------------------------------------------- exact scan (fallback, any k)
+struct ExactScanParams {
+    const float* rows; uint32_t ld; uint32_t dim; uint32_t n_rows;
+    const float* q; const float* qnorm;                // one padded query row and its exact-order norm
+    const float* nd;
+    const uint32_t* rowmask;
+    const uint32_t* idrank;                            // may be null: rank == row
+    int metric;
+    uint64_t* keys;                                    // [n_rows]: ordered(exact dist)<<32 | idrank, EMPTY if ineligible
+    uint32_t* status;
+};
+void launch_exact_scan(const ExactScanParams& p, hipStream_t s);
+
+struct EmitParams {                                    // sorted exact keys -> (id, dist) outputs
+    const uint64_t* keys; uint32_t cnt_max; const uint32_t* cnt;
+    const uint32_t* rank2row; const uint64_t* row_ids;
+    uint64_t* out_ids; float* out_dists; uint32_t* out_count; uint32_t k;
+};
+void launch_emit(const EmitParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------- multi-GPU partial merge
+void launch_merge_parts(const uint64_t* ids, const float* dists, const uint32_t* counts, uint32_t nparts,
+                        uint32_t nq, uint32_t k, uint64_t* out_ids, float* out_dists, uint32_t* out_counts,
+                        hipStream_t s);
+
+}  // namespace vdb

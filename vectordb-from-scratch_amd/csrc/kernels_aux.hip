@@ -1,0 +1,553 @@
+// kernels_aux.hip -- everything around the fused MFMA kernel: row statistics, query
+// preparation, dense sample scores (MFMA, no LDS), per-query radix select, exact
+// re-rank + certification, exact scan fallback, multi-GPU partial merge.
+// gfx950 only.  Built with -ffp-contract=off: the "exact" functions below must round
+// every multiply and add separately, like the reference's scalar Rust
+// (src/distance.rs:37-73, src/vector.rs:35-37).
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace vdb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// Exact-order arithmetic: sequential f32 left folds, one rounding per operation.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fold_sq(const float* __restrict__ x, uint32_t d) {
+    // vector.rs:35-37   sum_i x_i*x_i
+    float s = 0.0f;
+    uint32_t i = 0;
+    for (; i + 4 <= d; i += 4) {
+        float4 v = *reinterpret_cast<const float4*>(x + i);
+        s = __fadd_rn(s, __fmul_rn(v.x, v.x));
+        s = __fadd_rn(s, __fmul_rn(v.y, v.y));
+        s = __fadd_rn(s, __fmul_rn(v.z, v.z));
+        s = __fadd_rn(s, __fmul_rn(v.w, v.w));
+    }
+    for (; i < d; ++i) s = __fadd_rn(s, __fmul_rn(x[i], x[i]));
+    return s;
+}
+
+__device__ __forceinline__ float fold_dot(const float* __restrict__ q, const float* __restrict__ x, uint32_t d) {
+    // distance.rs:67-73   sum_i a_i*b_i
+    float s = 0.0f;
+    uint32_t i = 0;
+    for (; i + 4 <= d; i += 4) {
+        float4 a = *reinterpret_cast<const float4*>(q + i);
+        float4 b = *reinterpret_cast<const float4*>(x + i);
+        s = __fadd_rn(s, __fmul_rn(a.x, b.x));
+        s = __fadd_rn(s, __fmul_rn(a.y, b.y));
+        s = __fadd_rn(s, __fmul_rn(a.z, b.z));
+        s = __fadd_rn(s, __fmul_rn(a.w, b.w));
+    }
+    for (; i < d; ++i) s = __fadd_rn(s, __fmul_rn(q[i], x[i]));
+    return s;
+}
+
+__device__ __forceinline__ float fold_sqdiff(const float* __restrict__ q, const float* __restrict__ x, uint32_t d) {
+    // distance.rs:37-44   sum_i (a_i-b_i)^2   (powi(2) == t*t)
+    float s = 0.0f;
+    uint32_t i = 0;
+    for (; i + 4 <= d; i += 4) {
+        float4 a = *reinterpret_cast<const float4*>(q + i);
+        float4 b = *reinterpret_cast<const float4*>(x + i);
+        float t;
+        t = __fsub_rn(a.x, b.x); s = __fadd_rn(s, __fmul_rn(t, t));
+        t = __fsub_rn(a.y, b.y); s = __fadd_rn(s, __fmul_rn(t, t));
+        t = __fsub_rn(a.z, b.z); s = __fadd_rn(s, __fmul_rn(t, t));
+        t = __fsub_rn(a.w, b.w); s = __fadd_rn(s, __fmul_rn(t, t));
+    }
+    for (; i < d; ++i) { float t = __fsub_rn(q[i], x[i]); s = __fadd_rn(s, __fmul_rn(t, t)); }
+    return s;
+}
+
+// DistanceMetric::distance (distance.rs:20-33) for one (query, row) pair.
+// qn / xn are the exact-order norms of query and row (only read under Cosine).
+__device__ __forceinline__ float exact_distance(int metric, const float* __restrict__ q,
+                                                const float* __restrict__ x, uint32_t d, float qn, float xn) {
+    if (metric == EUCLID) return __fsqrt_rn(fold_sqdiff(q, x, d));
+    float dot = fold_dot(q, x, d);
+    if (metric == DOT) return -dot;
+    float den = __fmul_rn(qn, xn);                 // norm1 * norm2   distance.rs:58
+    float sim = __fdiv_rn(dot, den);
+    if (sim < -1.0f) sim = -1.0f;                  // f32::clamp keeps NaN
+    if (sim > 1.0f) sim = 1.0f;
+    return __fsub_rn(1.0f, sim);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row statistics at upload: exact-order norm and the (alpha, beta) of the ranking score
+//   score = fma(dot, alpha, beta):  Euclid  nd2 - 2 dot ; Cosine  -dot/|d| ; Dot  -dot
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_stats_kernel(RowStatsParams p) {
+    uint32_t row = p.row_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    float nd2 = 0.0f;
+    if (row < p.row_end) {
+        nd2 = fold_sq(p.rows + (size_t)row * p.ld, p.dim);
+        float nd = __fsqrt_rn(nd2);
+        p.nd[row] = nd;
+        float a, b;
+        if (p.metric == EUCLID) { a = -2.0f; b = nd2; }
+        else if (p.metric == COSINE) { a = -__fdiv_rn(1.0f, nd); b = 0.0f; }
+        else { a = -1.0f; b = 0.0f; }
+        p.alpha[row] = a;
+        p.beta[row] = b;
+    }
+    // wave max of the (non-negative or NaN) bit patterns, one atomic per wave
+    uint32_t bits = __float_as_uint(nd2) & 0x7fffffffu;
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(bits, o); bits = t > bits ? t : bits; }
+    if ((threadIdx.x & 63) == 0 && bits) atomicMax(p.nd2max_bits, bits);
+}
+void launch_row_stats(const RowStatsParams& p, hipStream_t s) {
+    uint32_t n = p.row_end - p.row_begin;
+    if (!n) return;
+    hipLaunchKernelGGL(row_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p);
+}
+
+__global__ __launch_bounds__(256) void count_zero_live_kernel(const float* nd, const uint32_t* livemask,
+                                                              uint32_t n_rows, uint32_t* out) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    bool z = false;
+    if (row < n_rows) {
+        bool live = livemask ? ((livemask[row >> 5] >> (row & 31)) & 1u) : true;
+        z = live && nd[row] == 0.0f;
+    }
+    unsigned long long b = __ballot(z);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(out, (uint32_t)__popcll(b));
+}
+void launch_count_zero_live(const float* nd, const uint32_t* livemask, uint32_t n_rows, uint32_t* out,
+                            hipStream_t s) {
+    if (!n_rows) return;
+    hipLaunchKernelGGL(count_zero_live_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, nd, livemask,
+                       n_rows, out);
+}
+
+__global__ __launch_bounds__(256) void build_rowmask_kernel(const uint64_t* row_ids, const uint32_t* livemask,
+                                                            const uint64_t* idmask, uint64_t mask_bits,
+                                                            uint32_t n_rows, uint32_t* out) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    bool ok = false;
+    if (row < n_rows) {
+        bool live = livemask ? ((livemask[row >> 5] >> (row & 31)) & 1u) : true;
+        uint64_t id = row_ids[row];
+        ok = live && id < mask_bits && ((idmask[id >> 6] >> (id & 63)) & 1ull);
+    }
+    unsigned long long b = __ballot(ok);
+    uint32_t lane = threadIdx.x & 63;
+    uint32_t w0 = (blockIdx.x * blockDim.x + (threadIdx.x & ~63u)) >> 5;
+    uint32_t nwords = (n_rows + 31) >> 5;
+    if (lane == 0 && w0 < nwords) out[w0] = (uint32_t)b;
+    if (lane == 1 && w0 + 1 < nwords) out[w0 + 1] = (uint32_t)(b >> 32);
+}
+void launch_build_rowmask(const uint64_t* row_ids, const uint32_t* livemask, const uint64_t* idmask,
+                          uint64_t mask_bits, uint32_t n_rows, uint32_t* out_mask, hipStream_t s) {
+    if (!n_rows) return;
+    hipLaunchKernelGGL(build_rowmask_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, row_ids, livemask,
+                       idmask, mask_bits, n_rows, out_mask);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Query preparation: copy into the zero-padded [nq_pad][ld] block the MFMA kernels read,
+// and compute each query's exact-order norm (one wave per query row; lane 0 folds).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepParams p) {
+    uint32_t q = blockIdx.x;
+    float* dst = p.qp + (size_t)q * p.ld;
+    const float* src = p.q_in + (size_t)q * p.dim;
+    for (uint32_t i = threadIdx.x; i < p.ld; i += blockDim.x)
+        dst[i] = (q < p.nq && i < p.dim) ? src[i] : 0.0f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float n = 0.0f;
+        if (q < p.nq) {
+            n = __fsqrt_rn(fold_sq(dst, p.dim));
+            if (p.metric == COSINE && n == 0.0f) atomicOr(p.status, ST_ZERO_QUERY);
+        }
+        p.qnorm[q] = n;
+        if (q >= p.nq) p.thr[q] = __uint_as_float(0xff800000u);   // -inf
+    }
+}
+void launch_query_prep(const QueryPrepParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(query_prep_kernel, dim3(p.nq_pad), dim3(256), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense scores of a row sample (or of every row when the index is small).  One wave =
+// one 32-row x 32-query tile on v_mfma_f32_32x32x2_f32, operands straight from global
+// memory.  The K order (groups of 8: k = 8g+s from lanes 0-31, 8g+4+s from lanes 32-63,
+// s = 0..3) and the score expression are EXACTLY those of the fused kernel, so the two
+// produce bit-identical scores and the sample's kk-th score is a valid inclusive
+// threshold there.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sample_row(uint32_t j, uint32_t n_sample, uint32_t n_rows) {
+    return n_sample >= n_rows ? j : (uint32_t)(((uint64_t)j * n_rows) / n_sample);
+}
+
+__global__ __launch_bounds__(256) void dense_scores_kernel(DenseParams p) {
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t c = lane & 31, h = lane >> 5;
+    const uint32_t tile = blockIdx.x * 4 + w;
+    const uint32_t ntiles = (p.n_sample + 31) / 32;
+    if (tile >= ntiles) return;                       // whole wave exits together
+    uint32_t sj = tile * 32 + c;
+    if (sj >= p.n_sample) sj = p.n_sample - 1;
+    const uint32_t srow = sample_row(sj, p.n_sample, p.n_rows);
+    const float* ap = p.rows + (size_t)srow * p.ld + 4 * h;
+    const float* bp = p.qp + (size_t)(blockIdx.y * 32 + c) * p.ld + 4 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const uint32_t ngroups = p.ld / 8;
+#pragma unroll 4
+    for (uint32_t g = 0; g < ngroups; ++g) {
+        float4 a = *reinterpret_cast<const float4*>(ap + 8 * g);
+        float4 b = *reinterpret_cast<const float4*>(bp + 8 * g);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    // C/D layout: column (query) = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const uint32_t q = blockIdx.y * 32 + c;
+    uint64_t* out = p.keys + (size_t)q * p.key_stride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        uint32_t j = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (j < p.n_sample) {
+            uint32_t row = sample_row(j, p.n_sample, p.n_rows);
+            bool ok = p.rowmask ? ((p.rowmask[row >> 5] >> (row & 31)) & 1u) : true;
+            float sc = fmaf(acc[r], p.alpha[row], p.beta[row]);
+            out[j] = ok ? make_key(sc, row) : EMPTY_KEY;
+        }
+    }
+}
+void launch_dense_scores(const DenseParams& p, hipStream_t s) {
+    uint32_t ntiles = (p.n_sample + 31) / 32;
+    if (!ntiles) return;
+    hipLaunchKernelGGL(dense_scores_kernel, dim3((ntiles + 3) / 4, p.nq_pad / 32), dim3(256), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-query radix select: the kk smallest of n 64-bit keys (all distinct: the low word is
+// a row), written sorted ascending.  One 256-thread workgroup per query; 8 MSB-first
+// digit passes find the kk-th key exactly, one pass collects, a bitonic network sorts.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t SEL_LDS_KEYS = 4096;   // keys cached in LDS when n fits
+constexpr uint32_t SEL_MAX_KK = 2048;
+
+__global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
+    __shared__ uint64_t sKeys[SEL_LDS_KEYS];
+    __shared__ uint64_t sOut[SEL_MAX_KK];
+    __shared__ uint32_t sHist[256];
+    __shared__ uint32_t sDigit, sRemain, sOutCnt, sValid;
+
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const uint64_t* keys = p.keys + (size_t)q * p.stride;
+    uint32_t n = p.n_fixed;
+    if (p.counts) {
+        uint32_t c = p.counts[q];
+        if (c > p.cap) { c = p.cap; if (p.ovf && tid == 0) p.ovf[q] = 1u; }
+        n = c;
+    }
+    const bool cached = n <= SEL_LDS_KEYS;
+    if (tid == 0) { sOutCnt = 0; sValid = 0; }
+    __syncthreads();
+    uint32_t myvalid = 0;
+    for (uint32_t i = tid; i < n; i += 256) {
+        uint64_t k = keys[i];
+        if (cached) sKeys[i] = k;
+        myvalid += (k != EMPTY_KEY);
+    }
+    for (int o = 32; o > 0; o >>= 1) myvalid += __shfl_xor(myvalid, o);
+    if (lane == 0 && myvalid) atomicAdd(&sValid, myvalid);
+    __syncthreads();
+    const uint32_t nvalid = sValid;
+    const uint32_t kk = nvalid < p.kk ? nvalid : p.kk;
+    uint64_t* out = p.out_keys + (size_t)q * p.out_stride;
+    if (kk == 0) {
+        for (uint32_t i = tid; i < p.kk; i += 256) out[i] = EMPTY_KEY;
+        if (tid == 0) { p.out_cnt[q] = 0; if (p.out_thr) p.out_thr[q] = __uint_as_float(0x7f800000u); }
+        return;
+    }
+    // ---- find the kk-th smallest key
+    uint64_t prefix = 0;
+    uint32_t remain = kk;
+    for (int b = 7; b >= 0; --b) {
+        sHist[tid] = 0;
+        __syncthreads();
+        const int shift = 8 * b;
+        for (uint32_t i = tid; i < n; i += 256) {
+            uint64_t k = cached ? sKeys[i] : keys[i];
+            bool in = (k != EMPTY_KEY) && (b == 7 || (k >> (shift + 8)) == prefix);
+            if (in) atomicAdd(&sHist[(uint32_t)(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            uint32_t c0 = sHist[4 * lane], c1 = sHist[4 * lane + 1], c2 = sHist[4 * lane + 2], c3 = sHist[4 * lane + 3];
+            uint32_t sum = c0 + c1 + c2 + c3, incl = sum;
+            for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o); if ((int)lane >= o) incl += t; }
+            unsigned long long hit = __ballot(incl >= remain);
+            int first = __ffsll((long long)hit) - 1;
+            if ((int)lane == first) {
+                uint32_t r = remain - (incl - sum);
+                uint32_t d = 0;
+                if (r > c0) { r -= c0; d = 1; if (r > c1) { r -= c1; d = 2; if (r > c2) { r -= c2; d = 3; } } }
+                sDigit = 4 * lane + d;
+                sRemain = r;
+            }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | sDigit;
+        remain = sRemain;
+        __syncthreads();
+    }
+    const uint64_t pivot = prefix;
+    // ---- collect keys <= pivot (exactly kk of them, keys are distinct)
+    for (uint32_t i = tid; i < n; i += 256) {
+        uint64_t k = cached ? sKeys[i] : keys[i];
+        if (k <= pivot) {     // EMPTY_KEY is the maximum and pivot is a real key, so it never passes
+            uint32_t slot = atomicAdd(&sOutCnt, 1u);
+            if (slot < SEL_MAX_KK) sOut[slot] = k;
+        }
+    }
+    __syncthreads();
+    uint32_t P = 2;
+    while (P < kk) P <<= 1;
+    for (uint32_t i = kk + tid; i < P; i += 256) sOut[i] = EMPTY_KEY;
+    __syncthreads();
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < P / 2; t += 256) {
+                uint32_t lo = 2 * t - (t & (stride - 1));      // index with bit `stride` cleared
+                uint32_t hi2 = lo + stride;
+                bool up = ((lo & size) == 0);
+                uint64_t a = sOut[lo], b2 = sOut[hi2];
+                if ((a > b2) == up) { sOut[lo] = b2; sOut[hi2] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t i = tid; i < p.kk; i += 256) out[i] = i < kk ? sOut[i] : EMPTY_KEY;
+    if (tid == 0) {
+        p.out_cnt[q] = kk;
+        if (p.out_thr)
+            p.out_thr[q] = (kk == p.kk) ? ordered_to_f32((uint32_t)(sOut[kk - 1] >> 32)) : __uint_as_float(0x7f800000u);
+    }
+}
+void launch_select(const SelectParams& p, uint32_t nq, hipStream_t s) {
+    if (!nq) return;
+    hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(256), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact re-rank of the kp candidates of each query + certification + final ordering.
+// One 128-thread workgroup per query, one candidate per thread.  Distances are computed
+// in the reference's exact operation order, so they are bit-identical to the CPU oracle.
+// Certification: every row NOT among the candidates has ranking score >= T (the kp-th
+// candidate's score).  From T we derive a lower bound LB on such a row's exact distance
+// (rounding-error bound eps); if the k-th exact distance is < LB, no
+// excluded row can enter the top k and the result is exact.  Otherwise cert[q] = 0 and
+// the host re-does that query with the exact scan.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void rerank_kernel(RerankParams p) {
+    __shared__ uint32_t sDist[128];     // ordered exact distance
+    __shared__ uint64_t sId[128];
+    __shared__ uint32_t sAnyNan, sNanKey;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t cnt = p.cand_cnt[q];
+    if (tid == 0) { sAnyNan = 0; sNanKey = 0; }
+    __syncthreads();
+    uint32_t od = 0xffffffffu;
+    uint64_t id = ~0ull;
+    if (tid < cnt) {
+        uint64_t key = p.cand[(size_t)q * p.cand_stride + tid];
+        uint32_t row = (uint32_t)key;
+        if ((uint32_t)(key >> 32) == 0u) sNanKey = 1u;      // approximate score was NaN
+        bool ok = row < p.n_rows && (p.rowmask ? ((p.rowmask[row >> 5] >> (row & 31)) & 1u) : true);
+        if (ok) {
+            float dist = exact_distance(p.metric, p.qp + (size_t)q * p.ld, p.rows + (size_t)row * p.ld, p.dim,
+                                        p.qnorm[q], p.nd[row]);
+            if (dist != dist) sAnyNan = 1u;
+            od = f32_to_ordered(dist);
+            id = p.row_ids[row];
+        }
+    }
+    sDist[tid] = od;
+    sId[tid] = id;
+    __syncthreads();
+    // bitonic sort of 128 (dist, id) pairs, ascending
+    for (uint32_t size = 2; size <= 128; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            if (tid < 64) {
+                uint32_t lo = 2 * tid - (tid & (stride - 1));
+                uint32_t hi = lo + stride;
+                bool up = ((lo & size) == 0);
+                uint32_t da = sDist[lo], db = sDist[hi];
+                uint64_t ia = sId[lo], ib = sId[hi];
+                bool gt = da > db || (da == db && ia > ib);
+                if (gt == up) { sDist[lo] = db; sDist[hi] = da; sId[lo] = ib; sId[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    // number of real candidates (ineligible ones sorted to the end with id ~0)
+    uint32_t real = 0;
+    {
+        unsigned long long b0 = __ballot(sId[tid] != ~0ull);
+        __shared__ uint32_t sReal[2];
+        if ((tid & 63) == 0) sReal[tid >> 6] = (uint32_t)__popcll(b0);
+        __syncthreads();
+        real = sReal[0] + sReal[1];
+    }
+    const uint32_t nout = real < p.k ? real : p.k;
+    if (tid < p.k) {
+        size_t o = (size_t)q * p.out_stride + tid;
+        if (tid < nout) { p.out_ids[o] = sId[tid]; p.out_dists[o] = ordered_to_f32(sDist[tid]); }
+        else { p.out_ids[o] = ~0ull; p.out_dists[o] = __uint_as_float(0x7fc00000u); }
+    }
+    if (tid == 0) {
+        p.out_counts[q] = nout;
+        if (sAnyNan) atomicOr(p.status, ST_NAN);
+        uint32_t cert = 1;
+        if (cnt == p.kp && nout > 0) {
+            // excluded rows may exist; T = score of the last candidate
+            float T = ordered_to_f32((uint32_t)(p.cand[(size_t)q * p.cand_stride + p.kp - 1] >> 32));
+            double ek = (double)ordered_to_f32(sDist[nout - 1]);
+            double qn = (double)p.qnorm[q];
+            double eps = (double)p.eps_coef;
+            double ndmax = sqrt((double)__uint_as_float(*p.nd2max_bits));
+            bool ok;
+            if (p.metric == DOT) {
+                ok = ek < (double)T - eps * qn * ndmax;
+            } else if (p.metric == COSINE) {
+                ok = ek < 1.0 + (double)T / qn - eps;
+            } else {
+                double s = qn + ndmax;
+                ok = ek * ek < (double)T + qn * qn - eps * (s * s + ek * ek);
+            }
+            // a NaN approximate score next to a non-NaN exact one, or fewer real rows than
+            // asked for while the candidate list was full, cannot be certified either
+            if (!ok || sNanKey || real < p.kp) cert = 0;
+            if (nout < p.k) cert = 0;
+        }
+        p.cert[q] = cert;
+    }
+}
+void launch_rerank(const RerankParams& p, uint32_t nq, hipStream_t s) {
+    if (!nq) return;
+    hipLaunchKernelGGL(rerank_kernel, dim3(nq), dim3(128), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact scan (fallback and large k): one thread per row, the reference's arithmetic, for
+// one query.  Keys carry the id rank so that the select orders by (distance, id).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void exact_scan_kernel(ExactScanParams p) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= p.n_rows) return;
+    bool ok = p.rowmask ? ((p.rowmask[row >> 5] >> (row & 31)) & 1u) : true;
+    uint64_t key = EMPTY_KEY;
+    if (ok) {
+        float dist = exact_distance(p.metric, p.q, p.rows + (size_t)row * p.ld, p.dim, p.qnorm[0], p.nd[row]);
+        if (dist != dist) atomicOr(p.status, ST_NAN);
+        uint32_t rk = p.idrank ? p.idrank[row] : row;
+        key = ((uint64_t)f32_to_ordered(dist) << 32) | rk;
+    }
+    p.keys[row] = key;
+}
+void launch_exact_scan(const ExactScanParams& p, hipStream_t s) {
+    if (!p.n_rows) return;
+    hipLaunchKernelGGL(exact_scan_kernel, dim3((p.n_rows + 255) / 256), dim3(256), 0, s, p);
+}
+
+__global__ __launch_bounds__(256) void emit_kernel(EmitParams p) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cnt = *p.cnt;
+    if (cnt > p.k) cnt = p.k;
+    if (i == 0) *p.out_count = cnt;
+    if (i >= p.k) return;
+    if (i < cnt) {
+        uint64_t key = p.keys[i];
+        uint32_t rk = (uint32_t)key;
+        uint32_t row = p.rank2row ? p.rank2row[rk] : rk;
+        p.out_ids[i] = p.row_ids[row];
+        p.out_dists[i] = ordered_to_f32((uint32_t)(key >> 32));
+    } else {
+        p.out_ids[i] = ~0ull;
+        p.out_dists[i] = __uint_as_float(0x7fc00000u);
+    }
+}
+void launch_emit(const EmitParams& p, hipStream_t s) {
+    if (!p.k) return;
+    hipLaunchKernelGGL(emit_kernel, dim3((p.k + 255) / 256), dim3(256), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU exchange: merge nparts sorted partial top-k lists per query by (distance, id).
+// One workgroup per query; nparts*k <= 2048 candidates sorted in LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t MERGE_MAX = 2048;
+__global__ __launch_bounds__(256) void merge_parts_kernel(const uint64_t* ids, const float* dists,
+                                                          const uint32_t* counts, uint32_t nparts, uint32_t nq,
+                                                          uint32_t k, uint64_t* out_ids, float* out_dists,
+                                                          uint32_t* out_counts) {
+    __shared__ uint32_t sD[MERGE_MAX];
+    __shared__ uint64_t sI[MERGE_MAX];
+    __shared__ uint32_t sTotal;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    const uint32_t total = nparts * k;
+    uint32_t P = 2;
+    while (P < total) P <<= 1;
+    if (tid == 0) sTotal = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < P; i += 256) {
+        uint32_t od = 0xffffffffu;
+        uint64_t id = ~0ull;
+        if (i < total) {
+            uint32_t part = i / k, j = i - part * k;
+            if (j < counts[(size_t)part * nq + q]) {
+                size_t o = ((size_t)part * nq + q) * k + j;
+                od = f32_to_ordered(dists[o]);
+                id = ids[o];
+                ++mine;
+            }
+        }
+        sD[i] = od;
+        sI[i] = id;
+    }
+    if (mine) atomicAdd(&sTotal, mine);
+    __syncthreads();
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < P / 2; t += 256) {
+                uint32_t lo = 2 * t - (t & (stride - 1));
+                uint32_t hi = lo + stride;
+                bool up = ((lo & size) == 0);
+                uint32_t da = sD[lo], db = sD[hi];
+                uint64_t ia = sI[lo], ib = sI[hi];
+                bool gt = da > db || (da == db && ia > ib);
+                if (gt == up) { sD[lo] = db; sD[hi] = da; sI[lo] = ib; sI[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t nout = sTotal < k ? sTotal : k;
+    for (uint32_t i = tid; i < k; i += 256) {
+        size_t o = (size_t)q * k + i;
+        if (i < nout) { out_ids[o] = sI[i]; out_dists[o] = ordered_to_f32(sD[i]); }
+        else { out_ids[o] = ~0ull; out_dists[o] = __uint_as_float(0x7fc00000u); }
+    }
+    if (tid == 0) out_counts[q] = nout;
+}
+void launch_merge_parts(const uint64_t* ids, const float* dists, const uint32_t* counts, uint32_t nparts,
+                        uint32_t nq, uint32_t k, uint64_t* out_ids, float* out_dists, uint32_t* out_counts,
+                        hipStream_t s) {
+    if (!nq || !k) return;
+    hipLaunchKernelGGL(merge_parts_kernel, dim3(nq), dim3(256), 0, s, ids, dists, counts, nparts, nq, k,
+                       out_ids, out_dists, out_counts);
+}
+
+}  // namespace vdb

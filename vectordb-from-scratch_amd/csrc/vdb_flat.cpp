@@ -1,0 +1,865 @@
+// vdb_flat.cpp -- host side of the C ABI declared in include/vdb_flat.h: the device-resident
+// mirror of the reference's FlatIndex (src/flat_index.rs:12-74) and the search pipeline that
+// drives the HIP kernels.  No CPU compute path exists here: every distance is produced on the
+// GPU, and every entry point fails with VDB_ERR_DEVICE when no HIP device is usable.
+//
+// Device layout (all in HBM, one allocation each, grown by doubling):
+//   rows     [cap][ld] f32   ld = dim rounded up to 32, zero padded (K stage of the MFMA kernel)
+//   nd       [cap]     f32   exact-order row norm  (vector.rs:35-37)
+//   alpha,beta [cap]   f32   ranking score = fma(dot, alpha, beta)
+//   row_ids  [cap]     u64   device row -> reference internal id
+//   live     [cap/32]  u32   tombstone bitmask (remove() clears a bit; rows are append-only)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/vdb_flat.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+thread_local size_t g_expected = 0, g_actual = 0;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+int fail_dim(size_t expected, size_t actual) {
+    g_expected = expected;
+    g_actual = actual;
+    // same text as error.rs:12
+    return fail(VDB_ERR_DIMENSION_MISMATCH, "Dimension mismatch: expected %zu, got %zu", expected, actual);
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(VDB_ERR_DEVICE, "HIP error %d (%s) at %s:%d: %s", (int)e_,              \
+                        hipGetErrorString(e_), __FILE__, __LINE__, #expr);                      \
+    } while (0)
+
+template <typename T> struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int ensure(size_t want) {
+        if (want <= n) return VDB_OK;
+        size_t cap = std::max(want, n + n / 2);
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+        HIP_TRY(hipMalloc((void**)&p, cap * sizeof(T)));
+        n = cap;
+        return VDB_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+inline uint32_t pow2_ceil(uint64_t x) {
+    uint32_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+constexpr uint32_t SMALL_N = 16384;     // at or below: dense scores of every row, no fused pass
+constexpr uint32_t SUPER = 256;         // queries per pipeline pass
+constexpr uint32_t MAX_SELECT = 2048;   // select kernel capacity (kk)
+
+}  // namespace
+
+struct vdb_flat_index {
+    int metric = 0, device = 0;
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+    std::mutex mu;
+
+    uint32_t dim = 0, ld = 0;             // primary dimension and padded row stride (floats)
+    // host bookkeeping of the device rows
+    std::vector<uint64_t> row_ids;
+    std::vector<uint32_t> live;           // bit per row
+    std::unordered_map<uint64_t, uint32_t> id2row;
+    uint32_t n_live = 0;
+    bool ids_monotone = true;
+    // rows whose dimension differs from `dim` (reference add() has no check, flat_index.rs:38-41)
+    std::unordered_map<uint64_t, std::vector<float>> misfits;
+    // rows staged on the host, not yet uploaded: device rows [n_uploaded, row_ids.size())
+    std::vector<float> pending;
+    uint32_t n_uploaded = 0;
+    bool live_dirty = false;
+
+    // device store
+    float* d_rows = nullptr; float* d_nd = nullptr; float* d_alpha = nullptr; float* d_beta = nullptr;
+    uint64_t* d_row_ids = nullptr; uint32_t* d_live = nullptr; uint32_t* d_scalars = nullptr;  // [0]=nd2max bits [1]=zero count
+    uint32_t cap_rows = 0;
+    bool zero_valid = false; uint32_t zero_live = 0;
+    DevBuf<uint32_t> d_idrank, d_rank2row; bool rank_valid = false;
+
+    // search workspace
+    DevBuf<float> w_qp, w_qnorm, w_thr, w_qin, w_outd;
+    DevBuf<uint64_t> w_dense, w_samp, w_pool, w_cand, w_exact, w_exsel, w_mask_ids, w_outi;
+    DevBuf<uint32_t> w_cnt, w_rowmask, w_flags, w_outc;
+    uint32_t* h_flags = nullptr; size_t h_flags_n = 0;
+    uint64_t stats[8] = {0};
+
+    uint32_t n_rows() const { return (uint32_t)row_ids.size(); }
+    bool is_live(uint32_t r) const { return (live[r >> 5] >> (r & 31)) & 1u; }
+};
+
+namespace {
+
+using Index = vdb_flat_index;
+
+int set_device(const Index* ix) {
+    HIP_TRY(hipSetDevice(ix->device));
+    return VDB_OK;
+}
+
+// ------------------------------------------------------------------ device store management
+int grow(Index* ix, uint32_t need_rows) {
+    if (need_rows <= ix->cap_rows) return VDB_OK;
+    uint32_t cap = std::max<uint32_t>({need_rows, ix->cap_rows * 2u, 1024u});
+    cap = round_up(cap, 256);
+    float *rows = nullptr, *nd = nullptr, *al = nullptr, *be = nullptr;
+    uint64_t* ids = nullptr;
+    uint32_t* lv = nullptr;
+    size_t row_bytes = (size_t)ix->ld * sizeof(float);
+    HIP_TRY(hipMalloc((void**)&rows, (size_t)cap * row_bytes));
+    HIP_TRY(hipMalloc((void**)&nd, (size_t)cap * 4));
+    HIP_TRY(hipMalloc((void**)&al, (size_t)cap * 4));
+    HIP_TRY(hipMalloc((void**)&be, (size_t)cap * 4));
+    HIP_TRY(hipMalloc((void**)&ids, (size_t)cap * 8));
+    HIP_TRY(hipMalloc((void**)&lv, (size_t)cap / 8));
+    hipStream_t s = ix->stream;
+    uint32_t old = ix->n_uploaded;
+    if (old) {
+        HIP_TRY(hipMemcpyAsync(rows, ix->d_rows, (size_t)old * row_bytes, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(nd, ix->d_nd, (size_t)old * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(al, ix->d_alpha, (size_t)old * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(be, ix->d_beta, (size_t)old * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemcpyAsync(ids, ix->d_row_ids, (size_t)old * 8, hipMemcpyDeviceToDevice, s));
+    }
+    // zero the rest of the row block: the [dim, ld) padding columns must read as 0
+    HIP_TRY(hipMemsetAsync((char*)rows + (size_t)old * row_bytes, 0, (size_t)(cap - old) * row_bytes, s));
+    HIP_TRY(hipMemsetAsync(lv, 0, (size_t)cap / 8, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (ix->d_rows) {
+        (void)hipFree(ix->d_rows); (void)hipFree(ix->d_nd); (void)hipFree(ix->d_alpha);
+        (void)hipFree(ix->d_beta); (void)hipFree(ix->d_row_ids); (void)hipFree(ix->d_live);
+    }
+    ix->d_rows = rows; ix->d_nd = nd; ix->d_alpha = al; ix->d_beta = be; ix->d_row_ids = ids; ix->d_live = lv;
+    ix->cap_rows = cap;
+    ix->live_dirty = true;
+    return VDB_OK;
+}
+
+void free_store(Index* ix) {
+    if (ix->d_rows) {
+        (void)hipFree(ix->d_rows); (void)hipFree(ix->d_nd); (void)hipFree(ix->d_alpha);
+        (void)hipFree(ix->d_beta); (void)hipFree(ix->d_row_ids); (void)hipFree(ix->d_live);
+    }
+    ix->d_rows = ix->d_nd = ix->d_alpha = ix->d_beta = nullptr;
+    ix->d_row_ids = nullptr; ix->d_live = nullptr;
+    ix->cap_rows = 0;
+}
+
+// Reset to the empty state (keeps the handle, metric and workspace).
+void reset_rows(Index* ix) {
+    ix->row_ids.clear(); ix->live.clear(); ix->id2row.clear(); ix->pending.clear();
+    ix->n_live = 0; ix->n_uploaded = 0; ix->dim = 0; ix->ld = 0; ix->ids_monotone = true;
+    ix->zero_valid = false; ix->rank_valid = false; ix->live_dirty = false;
+    free_store(ix);
+    if (ix->d_scalars) (void)hipMemsetAsync(ix->d_scalars, 0, 8, ix->stream);
+}
+
+void kill_row(Index* ix, uint32_t row) {
+    ix->live[row >> 5] &= ~(1u << (row & 31));
+    --ix->n_live;
+    ix->live_dirty = true;
+    ix->zero_valid = false;
+}
+
+// Appends one primary-dimension row to the host staging area.
+void append_row(Index* ix, uint64_t id, const float* v) {
+    uint32_t row = ix->n_rows();
+    if (row && id <= ix->row_ids.back()) ix->ids_monotone = false;
+    ix->row_ids.push_back(id);
+    if ((row >> 5) >= ix->live.size()) ix->live.push_back(0u);
+    ix->live[row >> 5] |= 1u << (row & 31);
+    ++ix->n_live;
+    ix->id2row[id] = row;
+    size_t off = ix->pending.size();
+    ix->pending.resize(off + ix->ld, 0.0f);
+    memcpy(ix->pending.data() + off, v, (size_t)ix->dim * sizeof(float));
+    ix->live_dirty = true;
+    ix->zero_valid = false;
+    ix->rank_valid = false;
+}
+
+// When the last primary row is gone but rows of another dimension remain, the lowest-id
+// such dimension becomes the primary one.
+void promote_misfits(Index* ix) {
+    if (ix->n_live != 0 || ix->misfits.empty()) return;
+    uint64_t best = ~0ull;
+    for (auto& kv : ix->misfits) best = std::min(best, kv.first);
+    size_t nd = ix->misfits[best].size();
+    reset_rows(ix);
+    if (nd == 0) return;   // zero-length vectors stay host-side only
+    ix->dim = (uint32_t)nd;
+    ix->ld = round_up(ix->dim, vdb::KSTAGE);
+    std::vector<uint64_t> ids;
+    for (auto& kv : ix->misfits)
+        if (kv.second.size() == nd) ids.push_back(kv.first);
+    std::sort(ids.begin(), ids.end());
+    for (uint64_t id : ids) {
+        append_row(ix, id, ix->misfits[id].data());
+        ix->misfits.erase(id);
+    }
+}
+
+int remove_id(Index* ix, uint64_t id) {
+    auto it = ix->id2row.find(id);
+    if (it != ix->id2row.end()) {
+        kill_row(ix, it->second);
+        ix->id2row.erase(it);
+        if (ix->n_live == 0) {
+            if (ix->misfits.empty()) reset_rows(ix);
+            else promote_misfits(ix);
+        }
+        return VDB_OK;
+    }
+    ix->misfits.erase(id);   // absent id is Ok(()) (flat_index.rs:43-46)
+    return VDB_OK;
+}
+
+int add_one(Index* ix, uint64_t id, const float* v, size_t dim) {
+    remove_id(ix, id);   // HashMap::insert overwrites (flat_index.rs:39)
+    if (ix->n_live == 0 && ix->misfits.empty() && dim > 0) {
+        if (ix->dim != dim) { reset_rows(ix); }
+        ix->dim = (uint32_t)dim;
+        ix->ld = round_up(ix->dim, vdb::KSTAGE);
+    }
+    if (dim == ix->dim && dim > 0) {
+        append_row(ix, id, v);
+    } else {
+        ix->misfits[id] = std::vector<float>(v, v + dim);
+        if (ix->n_live == 0) promote_misfits(ix);
+    }
+    return VDB_OK;
+}
+
+int flush(Index* ix) {
+    hipStream_t s = ix->stream;
+    uint32_t n = ix->n_rows();
+    if (n > ix->n_uploaded) {
+        int rc = grow(ix, n);
+        if (rc) return rc;
+        uint32_t first = ix->n_uploaded, cnt = n - first;
+        HIP_TRY(hipMemcpyAsync(ix->d_rows + (size_t)first * ix->ld, ix->pending.data(),
+                               (size_t)cnt * ix->ld * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(ix->d_row_ids + first, ix->row_ids.data() + first, (size_t)cnt * 8,
+                               hipMemcpyHostToDevice, s));
+        vdb::RowStatsParams rp{ix->d_rows, ix->ld, ix->dim, first, n, ix->metric, ix->d_nd, ix->d_alpha,
+                               ix->d_beta, ix->d_scalars};
+        vdb::launch_row_stats(rp, s);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));   // pending is host memory about to be released
+        ix->pending.clear();
+        ix->pending.shrink_to_fit();
+        ix->n_uploaded = n;
+        ix->zero_valid = false;
+    }
+    if (ix->live_dirty && ix->d_live && n) {
+        HIP_TRY(hipMemcpyAsync(ix->d_live, ix->live.data(), ix->live.size() * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        ix->live_dirty = false;
+    }
+    return VDB_OK;
+}
+
+int ensure_zero_count(Index* ix) {
+    if (ix->zero_valid) return VDB_OK;
+    hipStream_t s = ix->stream;
+    HIP_TRY(hipMemsetAsync(ix->d_scalars + 1, 0, 4, s));
+    vdb::launch_count_zero_live(ix->d_nd, ix->d_live, ix->n_uploaded, ix->d_scalars + 1, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&ix->zero_live, ix->d_scalars + 1, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    ix->zero_valid = true;
+    return VDB_OK;
+}
+
+// id rank tables so that exact-scan keys order by (distance, id) even when ids were not
+// appended in increasing order.
+int ensure_ranks(Index* ix) {
+    if (ix->ids_monotone || ix->rank_valid) return VDB_OK;
+    uint32_t n = ix->n_rows();
+    std::vector<uint32_t> order(n), rank(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return ix->row_ids[a] != ix->row_ids[b] ? ix->row_ids[a] < ix->row_ids[b] : a < b;
+    });
+    for (uint32_t r = 0; r < n; ++r) rank[order[r]] = r;
+    int rc;
+    if ((rc = ix->d_idrank.ensure(n)) || (rc = ix->d_rank2row.ensure(n))) return rc;
+    HIP_TRY(hipMemcpyAsync(ix->d_idrank.p, rank.data(), (size_t)n * 4, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(hipMemcpyAsync(ix->d_rank2row.p, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    ix->rank_valid = true;
+    return VDB_OK;
+}
+
+// Certification coefficient (DESIGN.md "certified top-k"): worst-case rounding bound of the
+// MFMA fma chain plus the oracle's sequential fold, K = padded row length.  VDB_EPS_SCALE
+// scales it (diagnostics only).
+float eps_coef(const Index* ix) {
+    const double u = 5.9604644775390625e-08;   // 2^-24
+    double K = (double)ix->ld;
+    double c;
+    if (ix->metric == vdb::EUCLID) c = (K + 4.0) * u;
+    else if (ix->metric == vdb::COSINE) c = (2.0 * K + 16.0) * u;
+    else c = (2.0 * K + 2.0) * u;
+    c *= 1.1;
+    if (const char* e = getenv("VDB_EPS_SCALE")) c *= atof(e);
+    return (float)c;
+}
+
+uint32_t pick_kp(size_t k) {
+    size_t want = k + std::max<size_t>(6, k / 5);
+    if (want <= 32) return 32;
+    if (want <= 64) return 64;
+    if (want <= 128) return 128;
+    return 0;   // exact-scan path
+}
+
+// ------------------------------------------------------------------ exact path for one query
+int exact_one(Index* ix, hipStream_t s, uint32_t q, size_t k, const uint32_t* d_rowmask, uint64_t* d_out_ids,
+              float* d_out_dists, uint32_t* d_out_count, float qnorm_unused) {
+    (void)qnorm_unused;
+    int rc;
+    uint32_t n = ix->n_uploaded;
+    if ((rc = ensure_ranks(ix))) return rc;
+    if ((rc = ix->w_exact.ensure(n))) return rc;
+    if ((rc = ix->w_exsel.ensure(MAX_SELECT))) return rc;
+    if ((rc = ix->w_cnt.ensure(4 * SUPER + 16))) return rc;
+    if (k > MAX_SELECT)
+        return fail(VDB_ERR_INVALID_ARGUMENT, "k = %zu exceeds the exact path's limit of %u", k, MAX_SELECT);
+    vdb::ExactScanParams ep{ix->d_rows, ix->ld, ix->dim, n, ix->w_qp.p + (size_t)q * ix->ld, ix->w_qnorm.p + q, ix->d_nd,
+                            d_rowmask, ix->ids_monotone ? nullptr : ix->d_idrank.p, ix->metric, ix->w_exact.p,
+                            ix->w_flags.p};
+    vdb::launch_exact_scan(ep, s);
+    uint32_t* cnt = ix->w_cnt.p + 4 * SUPER;
+    vdb::SelectParams sp{};
+    sp.keys = ix->w_exact.p; sp.stride = 0; sp.counts = nullptr; sp.n_fixed = n; sp.cap = n;
+    sp.kk = (uint32_t)k; sp.out_keys = ix->w_exsel.p; sp.out_stride = MAX_SELECT; sp.out_cnt = cnt;
+    sp.out_thr = nullptr; sp.ovf = nullptr;
+    vdb::launch_select(sp, 1, s);
+    vdb::EmitParams em{ix->w_exsel.p, MAX_SELECT, cnt, ix->ids_monotone ? nullptr : ix->d_rank2row.p,
+                       ix->d_row_ids, d_out_ids, d_out_dists, d_out_count, (uint32_t)k};
+    vdb::launch_emit(em, s);
+    HIP_TRY(hipGetLastError());
+    return VDB_OK;
+}
+
+// ------------------------------------------------------------------ the batched search
+int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, const uint64_t* d_idmask,
+                  size_t mask_bits, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
+                  hipStream_t user_stream) {
+    int rc;
+    if ((rc = set_device(ix))) return rc;
+    if ((rc = flush(ix))) return rc;
+    if (nq == 0) return VDB_OK;
+    // all launches of this search go to the caller's stream when one is given (so that the caller's
+    // events bracket them); the workspace is protected by the handle mutex and the final sync
+    hipStream_t s = user_stream ? user_stream : ix->stream;
+    memset(ix->stats, 0, sizeof(ix->stats));
+    size_t total_rows = ix->n_live + ix->misfits.size();
+    if (total_rows == 0 || k == 0) {   // storage.rs:218-220: empty store -> Ok(vec![]) before any check
+        HIP_TRY(hipMemsetAsync(d_out_counts, 0, nq * 4, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return VDB_OK;
+    }
+    // distance.rs:21-26: the first row whose dimension differs from the query's fails the search
+    if (ix->n_live && ix->dim != dim) return fail_dim(dim, ix->dim);
+    for (auto& kv : ix->misfits)
+        if (kv.second.size() != dim) return fail_dim(dim, kv.second.size());
+    if (!ix->misfits.empty()) {
+        // every stored row has the query's dimension but none is on the device (zero-length rows)
+        return fail(VDB_ERR_INVALID_ARGUMENT, "zero-dimensional vectors are not searchable");
+    }
+    if (ix->metric == vdb::COSINE) {
+        if ((rc = ensure_zero_count(ix))) return rc;
+        if (ix->zero_live)   // distance.rs:51-55 aborts the whole search (flat_index.rs:57-60)
+            return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
+    }
+    if (nq > 0x7fffffffull / 2 || k > 0x7fffffffull) return fail(VDB_ERR_INVALID_ARGUMENT, "batch too large");
+
+    const uint32_t n = ix->n_uploaded;
+    const uint32_t ld = ix->ld;
+    const uint32_t nq32 = (uint32_t)nq;
+    const uint32_t bp_all = round_up(nq32, SUPER);
+    const uint32_t kp = pick_kp(k);
+    ix->stats[5] = kp;
+
+    // ---- workspace
+    if ((rc = ix->w_qp.ensure((size_t)bp_all * ld))) return rc;
+    if ((rc = ix->w_qnorm.ensure(bp_all))) return rc;
+    if ((rc = ix->w_thr.ensure(bp_all))) return rc;
+    if ((rc = ix->w_flags.ensure(4 + 2 * (size_t)nq32))) return rc;
+    if ((rc = ix->w_cnt.ensure(4 * SUPER + 16))) return rc;
+    if (ix->h_flags_n < 4 + 2 * (size_t)nq32) {
+        if (ix->h_flags) (void)hipHostFree(ix->h_flags);
+        ix->h_flags = nullptr;
+        ix->h_flags_n = 0;
+        size_t want = 4 + 2 * (size_t)nq32 + 1024;
+        HIP_TRY(hipHostMalloc((void**)&ix->h_flags, want * 4, hipHostMallocDefault));
+        ix->h_flags_n = want;
+    }
+    uint32_t* d_status = ix->w_flags.p;        // [0] status bits
+    uint32_t* d_cert = ix->w_flags.p + 4;      // [nq]
+    uint32_t* d_ovf = d_cert + nq32;           // [nq]
+    HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, (4 + 2 * (size_t)nq32) * 4, s));
+
+    // ---- eligibility mask: tombstones, optionally AND the caller's id filter
+    const uint32_t* d_rowmask = (ix->n_live == n) ? nullptr : ix->d_live;
+    if (d_idmask) {
+        if ((rc = ix->w_rowmask.ensure((n + 31) / 32))) return rc;
+        vdb::launch_build_rowmask(ix->d_row_ids, d_rowmask, d_idmask, mask_bits, n, ix->w_rowmask.p, s);
+        d_rowmask = ix->w_rowmask.p;
+    }
+
+    // ---- queries: zero-padded copy + exact-order norms
+    {
+        vdb::QueryPrepParams qp{d_q, (uint32_t)dim, nq32, ix->w_qp.p, ld, bp_all, ix->w_qnorm.p, ix->w_thr.p, ix->metric, d_status};
+        vdb::launch_query_prep(qp, s);
+    }
+
+    if (kp == 0) {
+        // large k: exact scan for every query
+        HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (ix->h_flags[0] & vdb::ST_ZERO_QUERY)
+            return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
+        for (uint32_t q = 0; q < nq32; ++q) {
+            if ((rc = exact_one(ix, s, q, k, d_rowmask, d_out_ids + (size_t)q * k, d_out_dists + (size_t)q * k,
+                                d_out_counts + q, 0.f)))
+                return rc;
+        }
+        ix->stats[1] = nq32;
+        HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (ix->h_flags[0] & vdb::ST_NAN) return fail(VDB_ERR_NAN, "NaN distance (the reference panics here, flat_index.rs:62)");
+        return VDB_OK;
+    }
+
+    // ---- sizes of the threshold sample and the candidate pools
+    const bool small = n <= SMALL_N;
+    uint32_t S = small ? n : std::min<uint32_t>(16384u, std::max<uint32_t>(2048u, pow2_ceil(n / 256u)));
+    if (const char* e = getenv("VDB_SAMPLE")) { if (!small) S = std::min<uint32_t>(n, std::max(64, atoi(e))); }
+    uint64_t expect = small ? 0 : (uint64_t)n * kp / S;
+    uint32_t capq = small ? 0 : std::min<uint32_t>(1u << 20, pow2_ceil(4 * expect + 1024));
+    if ((rc = ix->w_dense.ensure((size_t)SUPER * S))) return rc;
+    if ((rc = ix->w_cand.ensure((size_t)SUPER * kp))) return rc;
+    if (!small) {
+        if ((rc = ix->w_samp.ensure((size_t)SUPER * kp))) return rc;
+        if ((rc = ix->w_pool.ensure((size_t)SUPER * capq))) return rc;
+    }
+    uint32_t* d_cnt_a = ix->w_cnt.p;               // sample select counts
+    uint32_t* d_pool_cnt = ix->w_cnt.p + SUPER;    // pool fill
+    uint32_t* d_cand_cnt = ix->w_cnt.p + 2 * SUPER;
+    ix->stats[4] = S;
+    const float eps = eps_coef(ix);
+
+    for (uint32_t q0 = 0; q0 < nq32; q0 += SUPER) {
+        const uint32_t nb = std::min(SUPER, nq32 - q0);
+        const uint32_t tiles = (nb + 31) / 32;
+        const int nqt = tiles > 4 ? 8 : tiles > 2 ? 4 : tiles > 1 ? 2 : 1;
+        const float* qp0 = ix->w_qp.p + (size_t)q0 * ld;
+
+        vdb::DenseParams dp{ix->d_rows, ld, n, qp0, round_up(nb, 32), ix->d_alpha, ix->d_beta, d_rowmask, S,
+                            ix->w_dense.p, S};
+        vdb::launch_dense_scores(dp, s);
+
+        vdb::SelectParams sp{};
+        sp.keys = ix->w_dense.p; sp.stride = S; sp.counts = nullptr; sp.n_fixed = S; sp.cap = S; sp.kk = kp;
+        sp.out_stride = kp;
+        if (small) {
+            sp.out_keys = ix->w_cand.p; sp.out_cnt = d_cand_cnt; sp.out_thr = nullptr; sp.ovf = nullptr;
+            vdb::launch_select(sp, nb, s);
+        } else {
+            // thresholds: the sample's kp-th score (padding queries were given -inf by query_prep)
+            sp.out_keys = ix->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->w_thr.p + q0; sp.ovf = nullptr;
+            vdb::launch_select(sp, nb, s);
+            HIP_TRY(hipMemsetAsync(d_pool_cnt, 0, SUPER * 4, s));
+            vdb::FusedParams fp{ix->d_rows, ld, n, ix->w_qp.p, q0, ix->d_alpha, ix->d_beta, d_rowmask,
+                                ix->w_thr.p, ix->w_pool.p - (size_t)q0 * capq, d_pool_cnt - q0, capq,
+                                (uint32_t)std::min<uint32_t>((uint32_t)ix->n_cu, (n + 31) / 32)};
+            vdb::launch_fused(fp, nqt, 1, s);
+            ix->stats[3] += n;
+            vdb::SelectParams mp{};
+            mp.keys = ix->w_pool.p; mp.stride = capq; mp.counts = d_pool_cnt; mp.n_fixed = 0; mp.cap = capq;
+            mp.kk = kp; mp.out_keys = ix->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
+            mp.out_thr = nullptr; mp.ovf = d_ovf + q0;
+            vdb::launch_select(mp, nb, s);
+        }
+        vdb::RerankParams rp{};
+        rp.rows = ix->d_rows; rp.ld = ld; rp.dim = ix->dim; rp.n_rows = n;
+        rp.qp = qp0; rp.qnorm = ix->w_qnorm.p + q0; rp.nd = ix->d_nd; rp.row_ids = ix->d_row_ids;
+        rp.rowmask = d_rowmask; rp.cand = ix->w_cand.p; rp.cand_stride = kp; rp.cand_cnt = d_cand_cnt; rp.kp = kp;
+        rp.metric = ix->metric; rp.k = (uint32_t)k; rp.eps_coef = eps; rp.nd2max_bits = ix->d_scalars;
+        rp.out_ids = d_out_ids + (size_t)q0 * k; rp.out_dists = d_out_dists + (size_t)q0 * k;
+        rp.out_counts = d_out_counts + q0; rp.out_stride = (uint32_t)k; rp.cert = d_cert + q0; rp.status = d_status;
+        vdb::launch_rerank(rp, nb, s);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, (4 + 2 * (size_t)nq32) * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t status = ix->h_flags[0];
+    if (status & vdb::ST_ZERO_QUERY)
+        return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
+    // ---- exact fallback for the queries the MFMA path could not certify
+    uint32_t n_fallback = 0;
+    const bool force_exact = getenv("VDB_FORCE_EXACT") != nullptr;
+    for (uint32_t q = 0; q < nq32; ++q) {
+        bool cert = ix->h_flags[4 + q] != 0, ovf = ix->h_flags[4 + nq32 + q] != 0;
+        if (ovf) ++ix->stats[2];
+        if (!cert) ++ix->stats[6];
+        if (cert && !ovf && !force_exact) continue;
+        if ((rc = exact_one(ix, s, q, k, d_rowmask, d_out_ids + (size_t)q * k, d_out_dists + (size_t)q * k,
+                            d_out_counts + q, 0.f)))
+            return rc;
+        ++n_fallback;
+    }
+    ix->stats[0] = nq32 - n_fallback;
+    ix->stats[1] = n_fallback;
+    uint32_t st2 = status;
+    if (n_fallback) {
+        HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        st2 |= ix->h_flags[0];
+    }
+    if (st2 & vdb::ST_NAN)
+        return fail(VDB_ERR_NAN, "NaN distance (the reference panics here, flat_index.rs:62)");
+    return VDB_OK;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+int vdb_abi_version(void) { return 1; }
+const char* vdb_build_arch(void) { return "gfx950"; }
+
+void vdb_last_error(char* buf, size_t cap, size_t* expected, size_t* actual) {
+    if (buf && cap) {
+        size_t n = std::min(cap - 1, g_err.size());
+        memcpy(buf, g_err.data(), n);
+        buf[n] = 0;
+    }
+    if (expected) *expected = g_expected;
+    if (actual) *actual = g_actual;
+}
+
+int vdb_flat_create(int metric, int device, vdb_flat_index** out) {
+    if (!out) return fail(VDB_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    if (metric < 0 || metric > 2) return fail(VDB_ERR_INVALID_ARGUMENT, "unknown metric %d", metric);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(VDB_ERR_DEVICE, "no HIP device available: this engine has no CPU path");
+    if (device < 0 || device >= ndev) return fail(VDB_ERR_INVALID_ARGUMENT, "device %d out of range (%d)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(VDB_ERR_DEVICE, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
+    auto* ix = new vdb_flat_index();
+    ix->metric = metric;
+    ix->device = device;
+    ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ix;
+        return fail(VDB_ERR_DEVICE, "hipStreamCreate failed");
+    }
+    if (hipMalloc((void**)&ix->d_scalars, 16) != hipSuccess || hipMemset(ix->d_scalars, 0, 16) != hipSuccess) {
+        (void)hipStreamDestroy(ix->stream);
+        delete ix;
+        return fail(VDB_ERR_DEVICE, "hipMalloc failed");
+    }
+    *out = ix;
+    return VDB_OK;
+}
+
+void vdb_flat_destroy(vdb_flat_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    (void)hipStreamSynchronize(ix->stream);
+    free_store(ix);
+    if (ix->d_scalars) (void)hipFree(ix->d_scalars);
+    ix->d_idrank.release(); ix->d_rank2row.release();
+    ix->w_qp.release(); ix->w_qnorm.release(); ix->w_thr.release(); ix->w_qin.release(); ix->w_outd.release();
+    ix->w_dense.release(); ix->w_samp.release(); ix->w_pool.release(); ix->w_cand.release(); ix->w_exact.release();
+    ix->w_exsel.release(); ix->w_mask_ids.release(); ix->w_outi.release();
+    ix->w_cnt.release(); ix->w_rowmask.release(); ix->w_flags.release(); ix->w_outc.release();
+    if (ix->h_flags) (void)hipHostFree(ix->h_flags);
+    (void)hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+int vdb_flat_add(vdb_flat_index* ix, uint64_t id, const float* v, size_t dim) {
+    if (!ix || (!v && dim)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    return add_one(ix, id, v, dim);
+}
+
+int vdb_flat_add_bulk(vdb_flat_index* ix, const uint64_t* ids, uint64_t first_id, const float* rows, size_t n,
+                      size_t dim) {
+    if (!ix || (!rows && n && dim)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    if (ix->n_rows() + n > 0xfffffff0ull) return fail(VDB_ERR_INVALID_ARGUMENT, "more than 2^32 rows per index");
+    ix->row_ids.reserve(ix->row_ids.size() + n);
+    for (size_t i = 0; i < n; ++i) {
+        rc = add_one(ix, ids ? ids[i] : first_id + i, rows + i * dim, dim);
+        if (rc) return rc;
+        // bound the host staging area: upload every 64 MiB
+        if (ix->pending.size() * sizeof(float) >= (64u << 20)) {
+            if ((rc = flush(ix))) return rc;
+        }
+    }
+    return VDB_OK;
+}
+
+int vdb_flat_add_bulk_device(vdb_flat_index* ix, const uint64_t* ids, uint64_t first_id, const float* d_rows,
+                             size_t n, size_t dim) {
+    if (!ix || (!d_rows && n)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return VDB_OK;
+    if (dim == 0) return fail(VDB_ERR_INVALID_ARGUMENT, "dim must be > 0");
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    if (ix->n_rows() + n > 0xfffffff0ull) return fail(VDB_ERR_INVALID_ARGUMENT, "more than 2^32 rows per index");
+    if (ix->n_live == 0 && ix->misfits.empty()) {
+        if (ix->dim != dim) reset_rows(ix);
+        ix->dim = (uint32_t)dim;
+        ix->ld = round_up(ix->dim, vdb::KSTAGE);
+    }
+    if (dim != ix->dim) return fail_dim(ix->dim, dim);   // the device bulk path requires the index dimension
+    // overwrite semantics for ids already present
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t id = ids ? ids[i] : first_id + i;
+        if (!ix->id2row.empty() || !ix->misfits.empty()) remove_id(ix, id);
+    }
+    if (ix->dim != dim) {   // remove_id may have emptied and reset the index
+        ix->dim = (uint32_t)dim;
+        ix->ld = round_up(ix->dim, vdb::KSTAGE);
+    }
+    if ((rc = flush(ix))) return rc;
+    uint32_t first = ix->n_rows();
+    if ((rc = grow(ix, first + (uint32_t)n))) return rc;
+    hipStream_t s = ix->stream;
+    HIP_TRY(hipMemcpy2DAsync(ix->d_rows + (size_t)first * ix->ld, (size_t)ix->ld * 4, d_rows, dim * 4, dim * 4, n,
+                             hipMemcpyDeviceToDevice, s));
+    ix->row_ids.reserve(first + n);
+    ix->id2row.reserve(first + n);
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t id = ids ? ids[i] : first_id + i;
+        uint32_t row = first + (uint32_t)i;
+        if (row && id <= ix->row_ids.back()) ix->ids_monotone = false;
+        ix->row_ids.push_back(id);
+        if ((row >> 5) >= ix->live.size()) ix->live.push_back(0u);
+        ix->live[row >> 5] |= 1u << (row & 31);
+        ix->id2row[id] = row;
+    }
+    ix->n_live += (uint32_t)n;
+    HIP_TRY(hipMemcpyAsync(ix->d_row_ids + first, ix->row_ids.data() + first, n * 8, hipMemcpyHostToDevice, s));
+    vdb::RowStatsParams rp{ix->d_rows, ix->ld, ix->dim, first, first + (uint32_t)n, ix->metric, ix->d_nd,
+                           ix->d_alpha, ix->d_beta, ix->d_scalars};
+    vdb::launch_row_stats(rp, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    ix->n_uploaded = first + (uint32_t)n;
+    ix->live_dirty = true;
+    ix->zero_valid = false;
+    ix->rank_valid = false;
+    return VDB_OK;
+}
+
+int vdb_flat_remove(vdb_flat_index* ix, uint64_t id) {
+    if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    return remove_id(ix, id);
+}
+
+int vdb_flat_get_vector(vdb_flat_index* ix, uint64_t id, float* out, size_t cap, size_t* dim) {
+    if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    auto m = ix->misfits.find(id);
+    if (m != ix->misfits.end()) {
+        if (dim) *dim = m->second.size();
+        if (out) memcpy(out, m->second.data(), std::min(cap, m->second.size()) * sizeof(float));
+        return VDB_OK;
+    }
+    auto it = ix->id2row.find(id);
+    if (it == ix->id2row.end()) return fail(VDB_ERR_NOT_FOUND, "Vector not found: %llu", (unsigned long long)id);
+    if (dim) *dim = ix->dim;
+    if (!out) return VDB_OK;
+    size_t ncopy = std::min<size_t>(cap, ix->dim);
+    uint32_t row = it->second;
+    if (row >= ix->n_uploaded) {
+        memcpy(out, ix->pending.data() + (size_t)(row - ix->n_uploaded) * ix->ld, ncopy * sizeof(float));
+    } else {
+        HIP_TRY(hipMemcpy(out, ix->d_rows + (size_t)row * ix->ld, ncopy * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return VDB_OK;
+}
+
+size_t vdb_flat_len(const vdb_flat_index* ix) { return ix ? ix->n_live + ix->misfits.size() : 0; }
+int vdb_flat_metric(const vdb_flat_index* ix) { return ix ? ix->metric : -1; }
+size_t vdb_flat_dim(const vdb_flat_index* ix) { return ix ? ix->dim : 0; }
+
+int vdb_flat_reserve(vdb_flat_index* ix, size_t rows, size_t dim) {
+    if (!ix || !dim) return fail(VDB_ERR_INVALID_ARGUMENT, "bad argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    if (ix->n_live == 0 && ix->misfits.empty()) {
+        if (ix->dim != dim) reset_rows(ix);
+        ix->dim = (uint32_t)dim;
+        ix->ld = round_up(ix->dim, vdb::KSTAGE);
+    }
+    if (dim != ix->dim) return fail_dim(ix->dim, dim);
+    if (rows > 0xfffffff0ull) return fail(VDB_ERR_INVALID_ARGUMENT, "more than 2^32 rows per index");
+    if ((rc = flush(ix))) return rc;
+    return grow(ix, (uint32_t)rows);
+}
+
+int vdb_flat_flush(vdb_flat_index* ix) {
+    if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    if ((rc = flush(ix))) return rc;
+    if (ix->metric == vdb::COSINE && ix->n_uploaded) return ensure_zero_count(ix);
+    return VDB_OK;
+}
+
+int vdb_flat_search_batch_device(vdb_flat_index* ix, const float* d_queries, size_t nq, size_t dim, size_t k,
+                                 const uint64_t* d_id_mask, size_t mask_bits, uint64_t* d_out_ids,
+                                 float* d_out_dists, uint32_t* d_out_counts, void* stream) {
+    if (!ix || (nq && (!d_queries || !d_out_counts || (k && (!d_out_ids || !d_out_dists)))))
+        return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    return search_device(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts,
+                         (hipStream_t)stream);
+}
+
+int vdb_flat_search_batch(vdb_flat_index* ix, const float* queries, size_t nq, size_t dim, const size_t* ks,
+                          size_t k, const uint64_t* id_mask, size_t mask_bits, size_t kstride, uint64_t* out_ids,
+                          float* out_dists, size_t* out_counts) {
+    if (!ix || (nq && (!queries || !out_counts))) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    size_t kmax = k;
+    if (ks) {
+        kmax = 0;
+        for (size_t b = 0; b < nq; ++b) kmax = std::max(kmax, ks[b]);
+    }
+    if (kmax > kstride) return fail(VDB_ERR_INVALID_ARGUMENT, "kstride %zu smaller than the largest k %zu", kstride, kmax);
+    if (kmax && nq && (!out_ids || !out_dists)) return fail(VDB_ERR_INVALID_ARGUMENT, "null output");
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    if (nq == 0) return VDB_OK;
+    // Index::search returns at most len results; clamp before sizing device buffers
+    size_t len = ix->n_live + ix->misfits.size();
+    size_t kdev = std::min(kmax, std::max<size_t>(len, 1));
+    hipStream_t s = ix->stream;
+    if ((rc = ix->w_qin.ensure(nq * std::max<size_t>(dim, 1)))) return rc;
+    if ((rc = ix->w_outi.ensure(nq * std::max<size_t>(kdev, 1)))) return rc;
+    if ((rc = ix->w_outd.ensure(nq * std::max<size_t>(kdev, 1)))) return rc;
+    if ((rc = ix->w_outc.ensure(nq))) return rc;
+    if (dim) HIP_TRY(hipMemcpyAsync(ix->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    const uint64_t* d_mask = nullptr;
+    if (id_mask) {
+        size_t words = (mask_bits + 63) / 64;
+        if ((rc = ix->w_mask_ids.ensure(std::max<size_t>(words, 1)))) return rc;
+        if (words) HIP_TRY(hipMemcpyAsync(ix->w_mask_ids.p, id_mask, words * 8, hipMemcpyHostToDevice, s));
+        d_mask = ix->w_mask_ids.p;
+    }
+    rc = search_device(ix, ix->w_qin.p, nq, dim, kdev, d_mask, mask_bits, ix->w_outi.p, ix->w_outd.p, ix->w_outc.p,
+                       nullptr);
+    if (rc) return rc;
+    std::vector<uint32_t> cnt(nq);
+    std::vector<uint64_t> ids(nq * std::max<size_t>(kdev, 1));
+    std::vector<float> ds(nq * std::max<size_t>(kdev, 1));
+    HIP_TRY(hipMemcpyAsync(cnt.data(), ix->w_outc.p, nq * 4, hipMemcpyDeviceToHost, s));
+    if (kdev) {
+        HIP_TRY(hipMemcpyAsync(ids.data(), ix->w_outi.p, nq * kdev * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ds.data(), ix->w_outd.p, nq * kdev * 4, hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t b = 0; b < nq; ++b) {
+        size_t kb = ks ? ks[b] : k;
+        size_t c = std::min<size_t>(cnt[b], kb);   // per-query k: a prefix of the batch-wide result
+        out_counts[b] = c;
+        for (size_t i = 0; i < c; ++i) {
+            out_ids[b * kstride + i] = ids[b * kdev + i];
+            out_dists[b * kstride + i] = ds[b * kdev + i];
+        }
+    }
+    return VDB_OK;
+}
+
+int vdb_flat_search(vdb_flat_index* ix, const float* query, size_t dim, size_t k, uint64_t* out_ids,
+                    float* out_dists, size_t* out_count) {
+    if (!out_count) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    return vdb_flat_search_batch(ix, query, 1, dim, nullptr, k, nullptr, 0, k, out_ids, out_dists, out_count);
+}
+
+int vdb_merge_topk_device(int device, const uint64_t* d_part_ids, const float* d_part_dists,
+                          const uint32_t* d_part_counts, size_t nparts, size_t nq, size_t k, uint64_t* d_out_ids,
+                          float* d_out_dists, uint32_t* d_out_counts, void* stream) {
+    if (!d_part_ids || !d_part_dists || !d_part_counts || !d_out_ids || !d_out_dists || !d_out_counts)
+        return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    if (nparts * k > 2048) return fail(VDB_ERR_INVALID_ARGUMENT, "nparts*k = %zu exceeds 2048", nparts * k);
+    HIP_TRY(hipSetDevice(device));
+    vdb::launch_merge_parts(d_part_ids, d_part_dists, d_part_counts, (uint32_t)nparts, (uint32_t)nq, (uint32_t)k,
+                            d_out_ids, d_out_dists, d_out_counts, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return VDB_OK;
+}
+
+int vdb_flat_last_stats(const vdb_flat_index* ix, uint64_t out[8]) {
+    if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    memcpy(out, ix->stats, sizeof(ix->stats));
+    return VDB_OK;
+}
+
+}  // extern "C"

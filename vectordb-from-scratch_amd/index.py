@@ -1,0 +1,222 @@
+"""Host-side mirror of the reference's `Index` trait (src/index.rs:11-35) and the GPU-backed
+implementation that replaces `FlatIndex` (src/flat_index.rs:12-74) behind it.
+
+`GpuFlatIndex` owns ids and a host copy of each row (the trait's `get_vector` returns a
+borrow, so the host keeps one anyway) and calls the hand-written HIP kernels through the C
+ABI of include/vdb_flat.h.  There is no CPU search path."""
+import abc
+import ctypes
+
+import numpy as np
+
+from . import _ffi
+from .error import DimensionMismatch, IndexError_, InvalidVector, NanDistance
+from .vector import DistanceMetric, Vector
+
+
+def _raise(rc):
+    msg, exp, act = _ffi.last_error()
+    if rc == _ffi.ERR_DIMENSION_MISMATCH:
+        raise DimensionMismatch(exp, act)
+    if rc == _ffi.ERR_INVALID_VECTOR:
+        raise InvalidVector(msg.split(": ", 1)[-1])
+    if rc == _ffi.ERR_NAN:
+        raise NanDistance(msg)
+    raise IndexError_(msg)
+
+
+class Index(abc.ABC):
+    """trait Index  (src/index.rs:11-35)"""
+
+    @abc.abstractmethod
+    def add(self, id, vector): ...
+
+    @abc.abstractmethod
+    def remove(self, id): ...
+
+    @abc.abstractmethod
+    def search(self, query, k): ...
+
+    @abc.abstractmethod
+    def get_vector(self, id): ...
+
+    @abc.abstractmethod
+    def metric(self): ...
+
+    @abc.abstractmethod
+    def len(self): ...
+
+    def is_empty(self):                              # index.rs:32-34
+        return self.len() == 0
+
+    def search_batch(self, queries):
+        """The provided method SURVEY.md 8(b) proposes adding to the trait: default = the
+        sequential loop of VectorStore::search_batch (storage.rs:306-309)."""
+        return [self.search(q, k) for q, k in queries]
+
+    def __len__(self):
+        return self.len()
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _u64p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+
+class GpuFlatIndex(Index):
+    """Drop-in for FlatIndex (src/flat_index.rs) backed by the MI355X engine."""
+
+    def __init__(self, metric, device=0, keep_host_copy=True):
+        self._metric = DistanceMetric(metric)
+        self._h = ctypes.c_void_p()
+        self._L = _ffi.lib()
+        rc = self._L.vdb_flat_create(int(self._metric), int(device), ctypes.byref(self._h))
+        if rc:
+            _raise(rc)
+        self._device = int(device)
+        self._keep = keep_host_copy
+        self._vectors = {}                           # id -> Vector (for get_vector borrows)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.vdb_flat_destroy(h)
+
+    # ---- Index trait
+    def add(self, id, vector):                       # flat_index.rs:38-41
+        v = vector if isinstance(vector, Vector) else Vector(vector)
+        rc = self._L.vdb_flat_add(self._h, int(id), _fp(v.data), v.dimension())
+        if rc:
+            _raise(rc)
+        if self._keep:
+            self._vectors[int(id)] = v
+
+    def remove(self, id):                            # flat_index.rs:43-46
+        rc = self._L.vdb_flat_remove(self._h, int(id))
+        if rc:
+            _raise(rc)
+        self._vectors.pop(int(id), None)
+
+    def get_vector(self, id):                        # flat_index.rs:48-50
+        if self._keep:
+            return self._vectors.get(int(id))
+        dim = ctypes.c_size_t()
+        rc = self._L.vdb_flat_get_vector(self._h, int(id), None, 0, ctypes.byref(dim))
+        if rc == _ffi.ERR_NOT_FOUND:
+            return None
+        if rc:
+            _raise(rc)
+        out = np.zeros(dim.value, dtype=np.float32)
+        rc = self._L.vdb_flat_get_vector(self._h, int(id), _fp(out), out.size, ctypes.byref(dim))
+        if rc:
+            _raise(rc)
+        return Vector(out)
+
+    def search(self, query, k):                      # flat_index.rs:52-65
+        q = query if isinstance(query, Vector) else Vector(query)
+        res = self.search_batch([(q, k)])
+        return res[0]
+
+    def metric(self):                                # flat_index.rs:67-69
+        return self._metric
+
+    def len(self):                                   # flat_index.rs:71-73
+        return int(self._L.vdb_flat_len(self._h))
+
+    # ---- batched hot call (overrides the provided loop)
+    def search_batch(self, queries, id_mask=None, mask_bits=0):
+        """queries: sequence of (Vector, k).  Returns a list of [(id, distance), ...] per query."""
+        if len(queries) == 0:
+            return []
+        dims = {q.dimension() for q, _ in queries}
+        if len(dims) != 1:
+            # a ragged batch: the reference handles each query on its own (storage.rs:306-309)
+            return [self.search_batch([(q, k)], id_mask, mask_bits)[0] for q, k in queries]
+        qs = np.stack([q.data for q, _ in queries]).astype(np.float32, copy=False)
+        ks = np.array([int(k) for _, k in queries], dtype=np.uintp)
+        ids, dists, counts = self.search_batch_arrays(qs, ks, id_mask=id_mask, mask_bits=mask_bits)
+        return [[(int(ids[b, i]), np.float32(dists[b, i])) for i in range(int(counts[b]))] for b in range(len(queries))]
+
+    def search_batch_arrays(self, queries, k, id_mask=None, mask_bits=0):
+        """numpy in/out form: queries [nq, dim] f32, k an int or a per-query array.
+        Returns (ids u64 [nq,kmax], dists f32 [nq,kmax], counts [nq])."""
+        qs = np.ascontiguousarray(queries, dtype=np.float32)
+        nq, dim = qs.shape
+        if np.isscalar(k):
+            ks_ptr, kscalar, kmax = None, int(k), int(k)
+        else:
+            ks = np.ascontiguousarray(k, dtype=np.uintp)
+            ks_ptr = ks.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t))
+            kscalar, kmax = 0, int(ks.max()) if ks.size else 0
+        kstride = max(kmax, 1)
+        out_ids = np.zeros((nq, kstride), dtype=np.uint64)
+        out_d = np.zeros((nq, kstride), dtype=np.float32)
+        counts = np.zeros(nq, dtype=np.uintp)
+        mask_ptr = None
+        if id_mask is not None:
+            m = np.ascontiguousarray(id_mask, dtype=np.uint64)
+            mask_ptr = _u64p(m)
+        rc = self._L.vdb_flat_search_batch(self._h, _fp(qs), nq, dim, ks_ptr, kscalar, mask_ptr, int(mask_bits),
+                                           kstride, _u64p(out_ids), _fp(out_d),
+                                           counts.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)))
+        if rc:
+            _raise(rc)
+        return out_ids, out_d, counts
+
+    # ---- bulk build and device-resident entry points
+    def add_bulk(self, rows, ids=None, first_id=0):
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        n, dim = rows.shape
+        idp = None
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype=np.uint64)
+            idp = _u64p(ids)
+        rc = self._L.vdb_flat_add_bulk(self._h, idp, int(first_id), _fp(rows), n, dim)
+        if rc:
+            _raise(rc)
+        if self._keep:
+            for i in range(n):
+                self._vectors[int(ids[i]) if ids is not None else first_id + i] = Vector(rows[i])
+
+    def add_bulk_device(self, dev_ptr, n, dim, ids=None, first_id=0):
+        """rows already in this GPU's HBM (e.g. a torch tensor's data_ptr()); no host copy is kept."""
+        idp = None
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype=np.uint64)
+            idp = _u64p(ids)
+        rc = self._L.vdb_flat_add_bulk_device(self._h, idp, int(first_id), ctypes.c_void_p(dev_ptr), int(n), int(dim))
+        if rc:
+            _raise(rc)
+
+    def reserve(self, rows, dim):
+        rc = self._L.vdb_flat_reserve(self._h, int(rows), int(dim))
+        if rc:
+            _raise(rc)
+
+    def flush(self):
+        rc = self._L.vdb_flat_flush(self._h)
+        if rc:
+            _raise(rc)
+
+    def search_batch_device(self, q_ptr, nq, dim, k, out_ids_ptr, out_dists_ptr, out_counts_ptr, stream=0,
+                            mask_ptr=0, mask_bits=0):
+        """Everything resident in HBM: raw device pointers (uint64 ids, f32 dists, u32 counts)."""
+        rc = self._L.vdb_flat_search_batch_device(
+            self._h, ctypes.c_void_p(q_ptr), int(nq), int(dim), int(k), ctypes.c_void_p(mask_ptr or None),
+            int(mask_bits), ctypes.c_void_p(out_ids_ptr), ctypes.c_void_p(out_dists_ptr),
+            ctypes.c_void_p(out_counts_ptr), ctypes.c_void_p(stream or None))
+        if rc:
+            _raise(rc)
+
+    def last_stats(self):
+        out = (ctypes.c_uint64 * 8)()
+        self._L.vdb_flat_last_stats(self._h, out)
+        keys = ["mfma_queries", "exact_queries", "pool_overflows", "rows_scanned", "sample_rows", "kprime",
+                "uncertified", "reserved"]
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def dim(self):
+        return int(self._L.vdb_flat_dim(self._h))
