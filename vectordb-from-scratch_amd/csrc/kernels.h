@@ -94,6 +94,8 @@ struct SelectParams {
     uint32_t* out_cnt;
     float* out_thr;                                    // may be null: score of the kk-th key, +inf if fewer
     uint32_t* ovf;                                     // may be null: set when counts[q] > cap
+    const uint64_t* lo_excl;                           // may be null: only keys > lo_excl[q] take part (chunked large k)
+    uint64_t* out_last;                                // may be null: largest selected key per query (unchanged if none)
 };
 void launch_select(const SelectParams& p, uint32_t nq, hipStream_t s);
 
@@ -147,6 +149,7 @@ struct EmitParams {                                    // sorted exact keys -> (
     const uint64_t* keys; uint32_t cnt_max; const uint32_t* cnt;
     const uint32_t* rank2row; const uint64_t* row_ids;
     uint64_t* out_ids; float* out_dists; uint32_t* out_count; uint32_t k;
+    uint32_t accumulate;                               // 1: *out_count += n (chunked large k), 0: *out_count = n
 };
 void launch_emit(const EmitParams& p, hipStream_t s);
 

@@ -14,6 +14,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------
 // Exact-order arithmetic: sequential f32 left folds, one rounding per operation.
+// sqrt uses __builtin_sqrtf (correctly rounded expansion); HIP's __fsqrt_rn lowers to a bare
+// v_sqrt_f32 (1 ulp) on gfx950 and is NOT usable for bit parity.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fold_sq(const float* __restrict__ x, uint32_t d) {
     // vector.rs:35-37   sum_i x_i*x_i
@@ -67,7 +69,7 @@ __device__ __forceinline__ float fold_sqdiff(const float* __restrict__ q, const 
 // qn / xn are the exact-order norms of query and row (only read under Cosine).
 __device__ __forceinline__ float exact_distance(int metric, const float* __restrict__ q,
                                                 const float* __restrict__ x, uint32_t d, float qn, float xn) {
-    if (metric == EUCLID) return __fsqrt_rn(fold_sqdiff(q, x, d));
+    if (metric == EUCLID) return __builtin_sqrtf(fold_sqdiff(q, x, d));
     float dot = fold_dot(q, x, d);
     if (metric == DOT) return -dot;
     float den = __fmul_rn(qn, xn);                 // norm1 * norm2   distance.rs:58
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(RowStatsParams p) {
     float nd2 = 0.0f;
     if (row < p.row_end) {
         nd2 = fold_sq(p.rows + (size_t)row * p.ld, p.dim);
-        float nd = __fsqrt_rn(nd2);
+        float nd = __builtin_sqrtf(nd2);
         p.nd[row] = nd;
         float a, b;
         if (p.metric == EUCLID) { a = -2.0f; b = nd2; }
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepParams p) {
     if (threadIdx.x == 0) {
         float n = 0.0f;
         if (q < p.nq) {
-            n = __fsqrt_rn(fold_sq(dst, p.dim));
+            n = __builtin_sqrtf(fold_sq(dst, p.dim));
             if (p.metric == COSINE && n == 0.0f) atomicOr(p.status, ST_ZERO_QUERY);
         }
         p.qnorm[q] = n;
@@ -252,11 +254,14 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
         n = c;
     }
     const bool cached = n <= SEL_LDS_KEYS;
+    const bool has_lo = p.lo_excl != nullptr;
+    const uint64_t lo = has_lo ? p.lo_excl[q] : 0ull;
     if (tid == 0) { sOutCnt = 0; sValid = 0; }
     __syncthreads();
     uint32_t myvalid = 0;
     for (uint32_t i = tid; i < n; i += 256) {
         uint64_t k = keys[i];
+        if (has_lo && k <= lo) k = EMPTY_KEY;          // already emitted by an earlier chunk
         if (cached) sKeys[i] = k;
         myvalid += (k != EMPTY_KEY);
     }
@@ -280,6 +285,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
         const int shift = 8 * b;
         for (uint32_t i = tid; i < n; i += 256) {
             uint64_t k = cached ? sKeys[i] : keys[i];
+            if (!cached && has_lo && k <= lo) k = EMPTY_KEY;
             bool in = (k != EMPTY_KEY) && (b == 7 || (k >> (shift + 8)) == prefix);
             if (in) atomicAdd(&sHist[(uint32_t)(k >> shift) & 255u], 1u);
         }
@@ -307,6 +313,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
     // ---- collect keys <= pivot (exactly kk of them, keys are distinct)
     for (uint32_t i = tid; i < n; i += 256) {
         uint64_t k = cached ? sKeys[i] : keys[i];
+        if (!cached && has_lo && k <= lo) k = EMPTY_KEY;
         if (k <= pivot) {     // EMPTY_KEY is the maximum and pivot is a real key, so it never passes
             uint32_t slot = atomicAdd(&sOutCnt, 1u);
             if (slot < SEL_MAX_KK) sOut[slot] = k;
@@ -332,6 +339,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
     for (uint32_t i = tid; i < p.kk; i += 256) out[i] = i < kk ? sOut[i] : EMPTY_KEY;
     if (tid == 0) {
         p.out_cnt[q] = kk;
+        if (p.out_last) p.out_last[q] = sOut[kk - 1];
         if (p.out_thr)
             p.out_thr[q] = (kk == p.kk) ? ordered_to_f32((uint32_t)(sOut[kk - 1] >> 32)) : __uint_as_float(0x7f800000u);
     }
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitParams p) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cnt = *p.cnt;
     if (cnt > p.k) cnt = p.k;
-    if (i == 0) *p.out_count = cnt;
+    if (i == 0) *p.out_count = (p.accumulate ? *p.out_count : 0u) + cnt;
     if (i >= p.k) return;
     if (i < cnt) {
         uint64_t key = p.keys[i];

@@ -360,23 +360,28 @@ int exact_one(Index* ix, hipStream_t s, uint32_t q, size_t k, const uint32_t* d_
     uint32_t n = ix->n_uploaded;
     if ((rc = ensure_ranks(ix))) return rc;
     if ((rc = ix->w_exact.ensure(n))) return rc;
-    if ((rc = ix->w_exsel.ensure(MAX_SELECT))) return rc;
+    if ((rc = ix->w_exsel.ensure(MAX_SELECT + 8))) return rc;
     if ((rc = ix->w_cnt.ensure(4 * SUPER + 16))) return rc;
-    if (k > MAX_SELECT)
-        return fail(VDB_ERR_INVALID_ARGUMENT, "k = %zu exceeds the exact path's limit of %u", k, MAX_SELECT);
     vdb::ExactScanParams ep{ix->d_rows, ix->ld, ix->dim, n, ix->w_qp.p + (size_t)q * ix->ld, ix->w_qnorm.p + q, ix->d_nd,
                             d_rowmask, ix->ids_monotone ? nullptr : ix->d_idrank.p, ix->metric, ix->w_exact.p,
                             ix->w_flags.p};
     vdb::launch_exact_scan(ep, s);
     uint32_t* cnt = ix->w_cnt.p + 4 * SUPER;
-    vdb::SelectParams sp{};
-    sp.keys = ix->w_exact.p; sp.stride = 0; sp.counts = nullptr; sp.n_fixed = n; sp.cap = n;
-    sp.kk = (uint32_t)k; sp.out_keys = ix->w_exsel.p; sp.out_stride = MAX_SELECT; sp.out_cnt = cnt;
-    sp.out_thr = nullptr; sp.ovf = nullptr;
-    vdb::launch_select(sp, 1, s);
-    vdb::EmitParams em{ix->w_exsel.p, MAX_SELECT, cnt, ix->ids_monotone ? nullptr : ix->d_rank2row.p,
-                       ix->d_row_ids, d_out_ids, d_out_dists, d_out_count, (uint32_t)k};
-    vdb::launch_emit(em, s);
+    uint64_t* last = ix->w_exsel.p + MAX_SELECT;      // largest key emitted so far (one u64 after the sort area)
+    // k may be as large as the index: emit in chunks of MAX_SELECT, each chunk = the smallest keys
+    // strictly above the previous chunk's last key
+    for (size_t done = 0; done < k; done += MAX_SELECT) {
+        uint32_t kk = (uint32_t)std::min<size_t>(MAX_SELECT, k - done);
+        vdb::SelectParams sp{};
+        sp.keys = ix->w_exact.p; sp.stride = 0; sp.counts = nullptr; sp.n_fixed = n; sp.cap = n;
+        sp.kk = kk; sp.out_keys = ix->w_exsel.p; sp.out_stride = MAX_SELECT; sp.out_cnt = cnt;
+        sp.out_thr = nullptr; sp.ovf = nullptr;
+        sp.lo_excl = done ? last : nullptr; sp.out_last = last;
+        vdb::launch_select(sp, 1, s);
+        vdb::EmitParams em{ix->w_exsel.p, MAX_SELECT, cnt, ix->ids_monotone ? nullptr : ix->d_rank2row.p,
+                           ix->d_row_ids, d_out_ids + done, d_out_dists + done, d_out_count, kk, done ? 1u : 0u};
+        vdb::launch_emit(em, s);
+    }
     HIP_TRY(hipGetLastError());
     return VDB_OK;
 }
