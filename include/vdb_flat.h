@@ -138,11 +138,16 @@ int vdb_merge_topk_device(int device, const uint64_t *d_part_ids, const float *d
                           uint64_t *d_out_ids, float *d_out_dists, uint32_t *d_out_counts,
                           void *stream);
 
+/* Measurement hook for bench.py: when on, every search brackets its fused MFMA kernel launch
+ * with HIP events on the launch stream and vdb_flat_last_stats()[7] reports the kernel's
+ * duration in nanoseconds (summed over the launches of that search). */
+int vdb_flat_set_profile(vdb_flat_index *h, int on);
+
 /* Counters of the last search on this handle (diagnostics, tests, bench):
  *  [0] queries answered by the MFMA path   [1] queries re-done by the exact-scan fallback
  *  [2] candidate-pool overflows            [3] rows scanned by the fused kernel
  *  [4] sample rows used for the thresholds [5] k' (candidates kept per query)
- *  [6] uncertified queries                 [7] reserved */
+ *  [6] uncertified queries                 [7] fused-kernel time of the search, ns (profiling on) */
 int vdb_flat_last_stats(const vdb_flat_index *h, uint64_t out[8]);
 
 /* Thread-local message of the last failing call on this thread, plus the

@@ -121,6 +121,7 @@ struct vdb_flat_index {
     DevBuf<uint32_t> w_cnt, w_rowmask, w_flags, w_outc;
     uint32_t* h_flags = nullptr; size_t h_flags_n = 0;
     uint64_t stats[8] = {0};
+    bool profile = false; hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     uint32_t n_rows() const { return (uint32_t)row_ids.size(); }
     bool is_live(uint32_t r) const { return (live[r >> 5] >> (r & 31)) & 1u; }
@@ -519,7 +520,16 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
             vdb::FusedParams fp{ix->d_rows, ld, n, ix->w_qp.p, q0, ix->d_alpha, ix->d_beta, d_rowmask,
                                 ix->w_thr.p, ix->w_pool.p - (size_t)q0 * capq, d_pool_cnt - q0, capq,
                                 (uint32_t)std::min<uint32_t>((uint32_t)ix->n_cu, (n + 31) / 32)};
+            if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
             vdb::launch_fused(fp, nqt, 1, s);
+            if (ix->profile) {
+                // one super-tile per event pair: wait here so the pair can be reused (profiling mode only)
+                HIP_TRY(hipEventRecord(ix->ev1, s));
+                HIP_TRY(hipEventSynchronize(ix->ev1));
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+                ix->stats[7] += (uint64_t)((double)ms * 1e6);
+            }
             ix->stats[3] += n;
             vdb::SelectParams mp{};
             mp.keys = ix->w_pool.p; mp.stride = capq; mp.counts = d_pool_cnt; mp.n_fixed = 0; mp.cap = capq;
@@ -628,6 +638,7 @@ void vdb_flat_destroy(vdb_flat_index* ix) {
     ix->w_exsel.release(); ix->w_mask_ids.release(); ix->w_outi.release();
     ix->w_cnt.release(); ix->w_rowmask.release(); ix->w_flags.release(); ix->w_outc.release();
     if (ix->h_flags) (void)hipHostFree(ix->h_flags);
+    if (ix->ev0) { (void)hipEventDestroy(ix->ev0); (void)hipEventDestroy(ix->ev1); }
     (void)hipStreamDestroy(ix->stream);
     delete ix;
 }
@@ -858,6 +869,19 @@ int vdb_merge_topk_device(int device, const uint64_t* d_part_ids, const float* d
     vdb::launch_merge_parts(d_part_ids, d_part_dists, d_part_counts, (uint32_t)nparts, (uint32_t)nq, (uint32_t)k,
                             d_out_ids, d_out_dists, d_out_counts, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
+    return VDB_OK;
+}
+
+int vdb_flat_set_profile(vdb_flat_index* ix, int on) {
+    if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    if (on && !ix->ev0) {
+        HIP_TRY(hipEventCreate(&ix->ev0));
+        HIP_TRY(hipEventCreate(&ix->ev1));
+    }
+    ix->profile = on != 0;
     return VDB_OK;
 }
 

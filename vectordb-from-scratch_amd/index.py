@@ -215,8 +215,13 @@ class GpuFlatIndex(Index):
         out = (ctypes.c_uint64 * 8)()
         self._L.vdb_flat_last_stats(self._h, out)
         keys = ["mfma_queries", "exact_queries", "pool_overflows", "rows_scanned", "sample_rows", "kprime",
-                "uncertified", "reserved"]
+                "uncertified", "fused_kernel_ns"]
         return dict(zip(keys, [int(v) for v in out]))
+
+    def set_profile(self, on=True):
+        rc = self._L.vdb_flat_set_profile(self._h, int(bool(on)))
+        if rc:
+            _raise(rc)
 
     def dim(self):
         return int(self._L.vdb_flat_dim(self._h))

@@ -1,0 +1,124 @@
+"""Row-sharded FlatIndex across the GPUs of one node.
+
+One process per GPU.  Rank r owns a contiguous block of database rows as an ordinary
+`GpuFlatIndex`; ids stay global.  A batched search is
+    local search (fused MFMA kernel, exact re-rank)  ->  ONE all-gather of the partial top-k
+    (ids, distances, counts) over RCCL/xGMI  ->  merge of world*k candidates per query,
+and every rank ends with the global top-k.  The payload is B*k*12 bytes per rank, so the
+exchange is latency-bound.  Error status is reduced (MAX) so that a zero-norm row on any shard
+fails the whole batch on every rank, like the reference's single loop (flat_index.rs:57-60).
+
+torch is used for device memory, streams and torch.distributed only.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _ffi
+from .error import DimensionMismatch, InvalidVector, NanDistance, IndexError_, VectorDbError
+
+
+def shard_range(n_rows, rank, world):
+    """Contiguous row block of `rank`: [lo, hi).  Blocks differ by at most one row."""
+    base, rem = divmod(int(n_rows), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def merge_topk_torch(ids, dists, counts, k):
+    """Reference implementation of the exchange merge with torch ops (CPU or GPU tensors):
+    ids/dists [W, B, k], counts [W, B] -> global top-k ascending by (distance, id)."""
+    W, B, kk = ids.shape
+    valid = torch.arange(kk, device=ids.device).view(1, 1, kk) < counts.view(W, B, 1)
+    d = torch.where(valid, dists, torch.full_like(dists, float("inf"))).permute(1, 0, 2).reshape(B, W * kk)
+    i = torch.where(valid, ids, torch.full_like(ids, torch.iinfo(torch.int64).max)).permute(1, 0, 2).reshape(B, W * kk)
+    # stable two-key sort: by id first, then (stable) by distance
+    o1 = torch.sort(i, dim=1, stable=True).indices
+    d1, i1 = torch.gather(d, 1, o1), torch.gather(i, 1, o1)
+    o2 = torch.sort(d1, dim=1, stable=True).indices
+    d2, i2 = torch.gather(d1, 1, o2), torch.gather(i1, 1, o2)
+    total = counts.sum(0).clamp(max=k).to(torch.int32)
+    return i2[:, :k].contiguous(), d2[:, :k].contiguous(), total
+
+
+def merge_topk_hip(ids, dists, counts, k, stream=None):
+    """The same merge on the GPU through the C ABI (vdb_merge_topk_device)."""
+    W, B, kk = ids.shape
+    assert kk == k and ids.is_cuda and ids.dtype == torch.int64 and dists.dtype == torch.float32
+    counts = counts.to(torch.int32).contiguous()
+    out_i = torch.empty((B, k), dtype=torch.int64, device=ids.device)
+    out_d = torch.empty((B, k), dtype=torch.float32, device=ids.device)
+    out_c = torch.empty((B,), dtype=torch.int32, device=ids.device)
+    st = torch.cuda.current_stream(ids.device).cuda_stream if stream is None else stream
+    rc = _ffi.lib().vdb_merge_topk_device(ids.device.index or 0, ctypes.c_void_p(ids.data_ptr()),
+                                          ctypes.c_void_p(dists.data_ptr()), ctypes.c_void_p(counts.data_ptr()),
+                                          W, B, k, ctypes.c_void_p(out_i.data_ptr()), ctypes.c_void_p(out_d.data_ptr()),
+                                          ctypes.c_void_p(out_c.data_ptr()), ctypes.c_void_p(st))
+    if rc:
+        raise IndexError_(_ffi.last_error()[0])
+    return out_i, out_d, out_c
+
+
+_ERR_CODE = {DimensionMismatch: 1, InvalidVector: 2, NanDistance: 3}
+
+
+class ShardedSearcher:
+    """Drives one batched search over `world` row shards.
+
+    local_search(queries [B, d] tensor, k) -> (ids int64 [B, k], dists f32 [B, k], counts int32 [B])
+    on the shard this rank owns (normally `gpu_local_search(index)` below).
+    """
+
+    def __init__(self, local_search, rank=0, world=1, group=None, merge=None):
+        self.local_search, self.rank, self.world, self.group = local_search, rank, world, group
+        self.merge = merge
+
+    def search_batch(self, queries, k):
+        code = 0
+        err = None
+        try:
+            ids, dists, counts = self.local_search(queries, k)
+        except VectorDbError as e:            # keep the collective call pattern identical on every rank
+            err, code = e, _ERR_CODE.get(type(e), 4)
+            B = queries.shape[0]
+            ids = torch.zeros((B, k), dtype=torch.int64, device=queries.device)
+            dists = torch.zeros((B, k), dtype=torch.float32, device=queries.device)
+            counts = torch.zeros((B,), dtype=torch.int32, device=queries.device)
+        if self.world == 1:
+            if err:
+                raise err
+            return ids, dists, counts
+        B = ids.shape[0]
+        # one gather for each dtype (ids, distances) + counts; status rides in an extra counts slot
+        cnt_st = torch.cat([counts.to(torch.int32), torch.tensor([code], dtype=torch.int32, device=counts.device)])
+        g_ids = torch.empty((self.world, B, k), dtype=torch.int64, device=ids.device)
+        g_d = torch.empty((self.world, B, k), dtype=torch.float32, device=ids.device)
+        g_c = torch.empty((self.world, B + 1), dtype=torch.int32, device=ids.device)
+        dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(g_d, dists.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(g_c, cnt_st, group=self.group)
+        worst = int(g_c[:, B].max().item())
+        if worst:
+            if err:
+                raise err
+            raise {1: IndexError_, 2: InvalidVector, 3: NanDistance}.get(worst, IndexError_)(
+                "a shard on another rank failed the batch")
+        g_cnt = g_c[:, :B].contiguous()
+        merge = self.merge or (merge_topk_hip if ids.is_cuda else merge_topk_torch)
+        return merge(g_ids, g_d, g_cnt, k)
+
+
+def gpu_local_search(index):
+    """local_search callable over a GpuFlatIndex with everything resident in HBM."""
+    def run(queries, k):
+        B, d = queries.shape
+        dev = queries.device
+        ids = torch.empty((B, k), dtype=torch.int64, device=dev)
+        dists = torch.empty((B, k), dtype=torch.float32, device=dev)
+        counts = torch.empty((B,), dtype=torch.int32, device=dev)
+        index.search_batch_device(queries.data_ptr(), B, d, k, ids.data_ptr(), dists.data_ptr(), counts.data_ptr(),
+                                  stream=torch.cuda.current_stream(dev).cuda_stream)
+        return ids, dists, counts
+    return run
