@@ -89,6 +89,9 @@ struct SelectParams {
     const uint64_t* keys; size_t stride;               // per-query key block
     const uint32_t* counts; uint32_t n_fixed;          // counts != null: n = min(counts[q], cap)
     uint32_t cap;
+    // gather mode (n_sub > 0): the query's keys live in n_sub sub-pools of capacity capl,
+    // keys[(q*n_sub + s)*capl + j], j < sub_counts[q*n_sub + s]
+    const uint32_t* sub_counts; uint32_t n_sub; uint32_t capl;
     uint32_t kk;                                       // how many smallest keys to keep (<= 2048)
     uint64_t* out_keys; uint32_t out_stride;           // sorted ascending, padded with EMPTY_KEY
     uint32_t* out_cnt;
@@ -105,15 +108,19 @@ struct FusedParams {
     const float* qp;                                   // padded queries, row q_base is the first of this launch
     uint32_t q_base;
     const float* alpha; const float* beta;
-    const uint32_t* rowmask;                           // may be null
+    const uint32_t* rowmask;                           // NEVER null here: the live mask when there is no filter
     const float* thr;                                  // [nq_pad] inclusive threshold per query
-    uint64_t* pool; uint32_t* pool_cnt; uint32_t capq; // pool[q*capq + slot]
+    // candidate pools: one private sub-pool per (query, row range, row part, lane half):
+    //   sub = ((q*n_wg + range)*RP + part)*2 + half ; keys at pool[sub*capl ..], count at pool_cnt[sub]
+    uint64_t* pool; uint32_t* pool_cnt; uint32_t capl;
     uint32_t n_wg;                                     // row ranges = grid.x
+    uint32_t ablate;                                   // diagnostics only (VDB_FUSED_ABLATE): 1 skip MFMAs, 2 skip staging, 4 skip barriers, 8 skip epilogue
 };
 // nqt = number of 32-query tiles handled per workgroup (1, 2, 4 or 8); grid.y super-tiles of 32*nqt queries
 void launch_fused(const FusedParams& p, int nqt, uint32_t n_super, hipStream_t s);
 size_t fused_lds_bytes(int nqt);
 uint32_t fused_tile_rows(int nqt);
+uint32_t fused_subpools_per_query(int nqt, uint32_t n_wg);
 
 // ---------------------------------------------------------------- exact re-rank + certification
 struct RerankParams {

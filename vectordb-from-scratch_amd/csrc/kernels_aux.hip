@@ -236,34 +236,57 @@ void launch_dense_scores(const DenseParams& p, hipStream_t s) {
 // a row), written sorted ascending.  One 256-thread workgroup per query; 8 MSB-first
 // digit passes find the kk-th key exactly, one pass collects, a bitonic network sorts.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t SEL_LDS_KEYS = 4096;   // keys cached in LDS when n fits
+constexpr uint32_t SEL_LDS_KEYS = 16384;  // keys cached in LDS when n fits (128 KB)
 constexpr uint32_t SEL_MAX_KK = 2048;
 
 __global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
-    __shared__ uint64_t sKeys[SEL_LDS_KEYS];
-    __shared__ uint64_t sOut[SEL_MAX_KK];
+    extern __shared__ __attribute__((aligned(16))) uint64_t sdyn[];
+    uint64_t* sKeys = sdyn;                       // [SEL_LDS_KEYS]
+    uint64_t* sOut = sdyn + SEL_LDS_KEYS;         // [SEL_MAX_KK]
     __shared__ uint32_t sHist[256];
-    __shared__ uint32_t sDigit, sRemain, sOutCnt, sValid;
+    __shared__ uint32_t sDigit, sRemain, sOutCnt, sValid, sN;
 
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const uint64_t* keys = p.keys + (size_t)q * p.stride;
     uint32_t n = p.n_fixed;
-    if (p.counts) {
-        uint32_t c = p.counts[q];
-        if (c > p.cap) { c = p.cap; if (p.ovf && tid == 0) p.ovf[q] = 1u; }
-        n = c;
-    }
-    const bool cached = n <= SEL_LDS_KEYS;
+    bool cached;
     const bool has_lo = p.lo_excl != nullptr;
     const uint64_t lo = has_lo ? p.lo_excl[q] : 0ull;
-    if (tid == 0) { sOutCnt = 0; sValid = 0; }
+    if (tid == 0) { sOutCnt = 0; sValid = 0; sN = 0; }
     __syncthreads();
     uint32_t myvalid = 0;
-    for (uint32_t i = tid; i < n; i += 256) {
-        uint64_t k = keys[i];
-        if (has_lo && k <= lo) k = EMPTY_KEY;          // already emitted by an earlier chunk
-        if (cached) sKeys[i] = k;
-        myvalid += (k != EMPTY_KEY);
+    if (p.n_sub) {
+        // gather the query's private sub-pools (written by the fused kernel) into LDS
+        const uint32_t* sc = p.sub_counts + (size_t)q * p.n_sub;
+        const uint64_t* base = p.keys + (size_t)q * p.n_sub * p.capl;
+        bool over = false;
+        for (uint32_t s2 = tid; s2 < p.n_sub; s2 += 256) {
+            uint32_t c = sc[s2];
+            if (c > p.capl) { c = p.capl; over = true; }
+            for (uint32_t j = 0; j < c; ++j) {
+                uint64_t k = base[(size_t)s2 * p.capl + j];
+                uint32_t slot = atomicAdd(&sN, 1u);
+                if (slot < SEL_LDS_KEYS) { sKeys[slot] = k; myvalid += (k != EMPTY_KEY); }
+                else over = true;
+            }
+        }
+        if (over && p.ovf) p.ovf[q] = 1u;
+        __syncthreads();
+        n = sN < SEL_LDS_KEYS ? sN : SEL_LDS_KEYS;
+        cached = true;
+    } else {
+        if (p.counts) {
+            uint32_t c = p.counts[q];
+            if (c > p.cap) { c = p.cap; if (p.ovf && tid == 0) p.ovf[q] = 1u; }
+            n = c;
+        }
+        cached = n <= SEL_LDS_KEYS;
+        for (uint32_t i = tid; i < n; i += 256) {
+            uint64_t k = keys[i];
+            if (has_lo && k <= lo) k = EMPTY_KEY;          // already emitted by an earlier chunk
+            if (cached) sKeys[i] = k;
+            myvalid += (k != EMPTY_KEY);
+        }
     }
     for (int o = 32; o > 0; o >>= 1) myvalid += __shfl_xor(myvalid, o);
     if (lane == 0 && myvalid) atomicAdd(&sValid, myvalid);
@@ -346,7 +369,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
 }
 void launch_select(const SelectParams& p, uint32_t nq, hipStream_t s) {
     if (!nq) return;
-    hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(256), (SEL_LDS_KEYS + SEL_MAX_KK) * sizeof(uint64_t), s, p);
 }
 
 // ---------------------------------------------------------------------------------------------

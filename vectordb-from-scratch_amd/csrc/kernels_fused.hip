@@ -4,11 +4,15 @@
 // (score, row) keys to a per-query candidate pool.  The B x N score matrix never
 // exists in memory.   gfx950 (MI355X, CDNA4) only.
 //
-// Workgroup = 512 threads = 8 waves (2 per SIMD), one workgroup per CU.
-// Tile      = TR database rows x (32*NQT) queries, K staged 32 floats at a time.
+// Workgroup = 256 threads = 4 waves (one per SIMD); TWO workgroups are resident per CU
+//   (75 KB LDS, <= 256 VGPRs each) and run out of phase: while one is in its staging /
+//   barrier / epilogue phase the other keeps the SIMD's MFMA pipe busy.  (A single
+//   8-wave workgroup per CU measured 73 % MFMA-pipe utilisation: its two waves per
+//   SIMD hit every barrier together.  profiles/r01_a_pmc_fused_v1.json)
+// Tile      = 128 database rows x (32*NQT) queries, K staged 32 floats at a time.
 //   wave w: query tile qt = w % NQT, row part rp = w / NQT, MT accumulator tiles of
-//           32x32 (rows (rp*MT+i)*32.., i < MT).  Headline shape NQT = 8, MT = 4:
-//           128 rows x 256 queries, 64 accumulator VGPRs per lane, 113 KB LDS.
+//           32x32 (rows (rp*MT+i)*32.., i < MT).  Headline shape NQT = 4, MT = 4:
+//           128 rows x 128 queries, 64 accumulator VGPRs per lane.
 //   MFMA operand map (32x32x2): A[i=lane&31][k=lane>>5] = database row, B[k][j=lane&31]
 //   = query, so every lane owns ONE query column (its threshold lives in a register) and
 //   16 rows per tile: row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -24,57 +28,56 @@
 //   32-row blocks.
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace vdb {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int ROWB = 144;                 // padded LDS bytes per 32-float row
 
-// NQT = 32-query tiles per workgroup (1,2,4,8); MT = 32-row accumulator tiles per wave.
-// RP = 8/NQT waves share a query tile and split the tile's rows; TR = 32*MT*RP rows per tile.
-template <int NQT, int MT> struct FusedCfg {
-    static constexpr int RP = 8 / NQT;
+// NW  = waves per workgroup (4: two independent workgroups share a CU, one wave each per SIMD)
+// NQT = 32-query tiles per workgroup; MT = 32-row accumulator tiles per wave.
+// RP = NW/NQT waves share a query tile and split the tile's rows; TR = 32*MT*RP rows per tile.
+template <int NQT, int MT, int NW> struct FusedCfg {
+    static constexpr int NT = NW * 64;
+    static constexpr int RP = NW / NQT;
     static constexpr int TR = 32 * MT * RP;
     static constexpr int A_BYTES = TR * ROWB;
     static constexpr int B_BYTES = 32 * NQT * ROWB;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int CONST_OFF = 2 * STAGE_BYTES;           // alpha[3][TR] beta[3][TR] valid[3][TR/32]
     static constexpr int LDS_BYTES = CONST_OFF + 3 * TR * 4 * 2 + 3 * (TR / 32) * 4;
-    static constexpr int NA = (TR * 8) / 512;                   // A float4 loads per thread per stage
-    static constexpr int NB = (NQT * 256 + 511) / 512;          // B float4 loads per thread per stage
+    static constexpr int NA = (TR * 8) / NT;                    // A float4 loads per thread per stage
+    static constexpr int NB = (NQT * 256 + NT - 1) / NT;        // B float4 loads per thread per stage
+    static_assert(NA >= 1 && NA <= 4 && NB >= 1 && NB <= 4 && (NQT * 256) % NT == 0 && TR % 64 == 0 && TR <= NT, "unsupported shape");
 };
-// the four shipped shapes: (queries per workgroup, rows per tile)
-using Cfg8 = FusedCfg<8, 4>;   // 256 queries x 128 rows, 64 accumulator VGPRs per lane
-using Cfg4 = FusedCfg<4, 4>;   // 128 queries x 256 rows
-using Cfg2 = FusedCfg<2, 2>;   //  64 queries x 256 rows
-using Cfg1 = FusedCfg<1, 1>;   //  32 queries x 256 rows
+// shipped shapes (all 128-row tiles, 4 waves): queries per workgroup 128 / 64 / 32
+using CfgQ128 = FusedCfg<4, 4, 4>;   // headline: 128 queries x 128 rows, 64 accumulator VGPRs per lane, 75 KB LDS
+using CfgQ64 = FusedCfg<2, 2, 4>;
+using CfgQ32 = FusedCfg<1, 1, 4>;
 
 size_t fused_lds_bytes(int nqt) {
     switch (nqt) {
-    case 1: return Cfg1::LDS_BYTES;
-    case 2: return Cfg2::LDS_BYTES;
-    case 4: return Cfg4::LDS_BYTES;
-    default: return Cfg8::LDS_BYTES;
+    case 1: return CfgQ32::LDS_BYTES;
+    case 2: return CfgQ64::LDS_BYTES;
+    default: return CfgQ128::LDS_BYTES;
     }
 }
-uint32_t fused_tile_rows(int nqt) {
-    switch (nqt) {
-    case 1: return Cfg1::TR;
-    case 2: return Cfg2::TR;
-    case 4: return Cfg4::TR;
-    default: return Cfg8::TR;
-    }
-}
+uint32_t fused_tile_rows(int) { return 128; }
 
 #define VDB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define VDB_PIN() __builtin_amdgcn_sched_barrier(0)
 
-template <int NQT, int MT>
-__global__ __launch_bounds__(512, 2) void fused_score_filter_kernel(FusedParams p) {
-    using C = FusedCfg<NQT, MT>;
+template <int NQT, int MT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void fused_score_filter_kernel(FusedParams p) {
+    using C = FusedCfg<NQT, MT, NW>;
     constexpr int TR = C::TR;
+    constexpr int NT = C::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // per-tile row constants, 3 rotating slots: slot (t+1)%3 is written during tile t's last stage while
-    // slot t%3 is read by tile t's epilogue; with 3 slots this also holds when a tile is a single stage
+    // per-tile row constants, 3 rotating slots: the slot of tile t+1 is written during tile t's last
+    // stage while tile t's slot is still to be read by its epilogue; three slots keep that safe even
+    // when a tile is a single K stage
     float* sAlpha = reinterpret_cast<float*>(smem + C::CONST_OFF);      // [3][TR]
     float* sBeta = sAlpha + 3 * TR;                                     // [3][TR]
     uint32_t* sValid = reinterpret_cast<uint32_t*>(sBeta + 3 * TR);     // [3][TR/32]
@@ -90,80 +93,79 @@ __global__ __launch_bounds__(512, 2) void fused_score_filter_kernel(FusedParams 
     const uint32_t b1 = (uint32_t)(((uint64_t)(blockIdx.x + 1) * nblk) / p.n_wg);
     const uint32_t r0 = b0 * 32;
     const uint32_t r1 = (b1 * 32 < p.n_rows) ? b1 * 32 : p.n_rows;
-    if (r0 >= r1) return;
+    const uint32_t qwg = p.q_base + blockIdx.y * (32 * NQT);            // first query of this workgroup
+    const uint32_t q = qwg + qt * 32 + c;                              // this lane's query
+    // private candidate sub-pool of this lane: [query][row range][row part][lane half][capl]
+    const size_t sub = (((size_t)q * p.n_wg + blockIdx.x) * C::RP + rp) * 2 + h;
+    uint64_t* mypool = p.pool + sub * p.capl;
+    uint32_t pcnt = 0;                                                  // keys appended by this lane so far
+    if (r0 >= r1) {                                                     // empty range: publish the zero count
+        p.pool_cnt[sub] = 0;
+        return;
+    }
     const uint32_t ntiles = (r1 - r0 + TR - 1) / TR;
     const uint32_t KS = p.ld / KSTAGE;
     const uint32_t total = ntiles * KS;
-    const uint32_t qwg = p.q_base + blockIdx.y * (32 * NQT);            // first query of this workgroup
-    const uint32_t q = qwg + qt * 32 + c;                              // this lane's query
     const float thrq = p.thr[q];
     const float* __restrict__ grow = p.rows;
-    const float* __restrict__ gq = p.qp + (size_t)qwg * p.ld;
     const uint32_t ld = p.ld;
+    const uint32_t last_row = p.n_rows - 1;
 
-    // ---- staging registers (global -> VGPR -> LDS); named scalars, not arrays, so they stay in VGPRs
+    // ---- staging registers (global -> VGPR -> LDS); named scalars, not arrays, so they stay in VGPRs.
+    // ONE register set: during stage s, register i is written to LDS (stage s+1's data, loaded one
+    // stage ago) and immediately re-loaded with stage s+2's data, in the shadow of the MFMAs.
     float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
     ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
     float r_alpha = 0.f, r_beta = 0.f;
-    bool r_valid = false;
+    uint32_t r_mask = 0, r_bit = 0;
+    bool r_inrange = false;
+    // this thread always stages chunk (tid&7) of rows (tid>>3) + i*NT/8
+    const uint32_t srow = tid >> 3, schunk = (tid & 7) * 4;
+    const float* pb0 = p.qp + (size_t)(qwg + srow) * ld + schunk;       // B rows are fixed for the workgroup
+    const size_t pb_step = (size_t)(NT / 8) * ld;
+    const uint32_t lds_st = srow * ROWB + (tid & 7) * 16;               // staging write offset inside a tile image
 
-#define VDB_LA(I, REG)                                                                                          \
-    if constexpr (C::NA > (I)) {                                                                                \
-        uint32_t idx_ = (I) * 512 + tid;                                                                        \
-        uint32_t row_ = tr0_ + (idx_ >> 3);                                                                     \
-        if (row_ >= p.n_rows) row_ = p.n_rows - 1; /* in bounds; masked in the epilogue */                      \
-        REG = *reinterpret_cast<const float4*>(grow + (size_t)row_ * ld + ks_ * KSTAGE + (idx_ & 7) * 4);       \
+    // load register REG with its float4 of stage (TILE, KSI)
+#define VDB_LA(I, REG, TILE, KSI)                                                                      \
+    if constexpr (C::NA > (I)) {                                                                       \
+        uint32_t row_ = r0 + (TILE) * TR + srow + (I) * (NT / 8);                                      \
+        row_ = row_ > last_row ? last_row : row_; /* in bounds; masked in the epilogue */              \
+        REG = *reinterpret_cast<const float4*>(grow + (size_t)row_ * ld + (KSI) * KSTAGE + schunk);    \
     }
-#define VDB_LB(I, REG)                                                                                          \
-    if constexpr (C::NB > (I)) {                                                                                \
-        uint32_t idx_ = (I) * 512 + tid;                                                                        \
-        if (idx_ < NQT * 256)                                                                                   \
-            REG = *reinterpret_cast<const float4*>(gq + (size_t)(idx_ >> 3) * ld + ks_ * KSTAGE + (idx_ & 7) * 4); \
+#define VDB_LB(I, REG, KSI)                                                                            \
+    if constexpr (C::NB > (I)) { REG = *reinterpret_cast<const float4*>(pb0 + (I) * pb_step + (KSI) * KSTAGE); }
+    // row constants of tile TILE: loaded by every thread, every stage (thread t and t+TR load the same
+    // row; all VMEM in the loop is unconditional so that hipcc can count vmcnt exactly)
+#define VDB_LC(TILE)                                                                                   \
+    {                                                                                                  \
+        uint32_t row_ = r0 + (TILE) * TR + (tid % TR);                                                 \
+        r_inrange = row_ < r1;                                                                         \
+        const uint32_t rr_ = r_inrange ? row_ : last_row;                                              \
+        r_bit = rr_ & 31;                                                                              \
+        r_mask = p.rowmask[rr_ >> 5]; /* raw loads only: they are consumed one stage later (VDB_SC) */ \
+        r_alpha = p.alpha[rr_];                                                                        \
+        r_beta = p.beta[rr_];                                                                          \
     }
-#define ISSUE_LOADS(ST)                                                                                         \
-    {                                                                                                           \
-        const uint32_t tile_ = (ST) / KS, ks_ = (ST) - tile_ * KS;                                              \
-        const uint32_t tr0_ = r0 + tile_ * TR;                                                                  \
-        VDB_LA(0, ra0) VDB_LA(1, ra1) VDB_LA(2, ra2) VDB_LA(3, ra3)                                             \
-        VDB_LB(0, rb0) VDB_LB(1, rb1) VDB_LB(2, rb2) VDB_LB(3, rb3)                                             \
-        if (ks_ == 0 && tid < TR) {                                                                             \
-            uint32_t row_ = tr0_ + tid;                                                                         \
-            bool ok_ = row_ < r1;                                                                               \
-            uint32_t rr_ = ok_ ? row_ : p.n_rows - 1;                                                           \
-            if (ok_ && p.rowmask) ok_ = (p.rowmask[rr_ >> 5] >> (rr_ & 31)) & 1u;                               \
-            r_valid = ok_;                                                                                      \
-            r_alpha = p.alpha[rr_];                                                                             \
-            r_beta = ok_ ? p.beta[rr_] : __uint_as_float(0x7f800000u); /* +inf never passes a finite thr */     \
-        }                                                                                                       \
+    // store register REG into the LDS image BUF
+#define VDB_SA(I, REG, BUF)                                                                            \
+    if constexpr (C::NA > (I)) {                                                                       \
+        *reinterpret_cast<float4*>(smem + (BUF) * C::STAGE_BYTES + lds_st + (I) * (NT / 8) * ROWB) = REG; \
     }
-
-#define VDB_SA(I, REG)                                                                                          \
-    if constexpr (C::NA > (I)) {                                                                                \
-        uint32_t idx_ = (I) * 512 + tid;                                                                        \
-        *reinterpret_cast<float4*>(sa_ + (idx_ >> 3) * ROWB + (idx_ & 7) * 16) = REG;                           \
+#define VDB_SB(I, REG, BUF)                                                                            \
+    if constexpr (C::NB > (I)) {                                                                       \
+        *reinterpret_cast<float4*>(smem + (BUF) * C::STAGE_BYTES + C::A_BYTES + lds_st + (I) * (NT / 8) * ROWB) = REG; \
     }
-#define VDB_SB(I, REG)                                                                                          \
-    if constexpr (C::NB > (I)) {                                                                                \
-        uint32_t idx_ = (I) * 512 + tid;                                                                        \
-        if (idx_ < NQT * 256) *reinterpret_cast<float4*>(sb_ + (idx_ >> 3) * ROWB + (idx_ & 7) * 16) = REG;     \
-    }
-#define WRITE_LDS(ST)                                                                                           \
-    {                                                                                                           \
-        const uint32_t tile_ = (ST) / KS, ks_ = (ST) - tile_ * KS;                                              \
-        char* sa_ = smem + ((ST) & 1) * C::STAGE_BYTES;                                                         \
-        char* sb_ = sa_ + C::A_BYTES;                                                                           \
-        VDB_SA(0, ra0) VDB_SA(1, ra1) VDB_SA(2, ra2) VDB_SA(3, ra3)                                             \
-        VDB_SB(0, rb0) VDB_SB(1, rb1) VDB_SB(2, rb2) VDB_SB(3, rb3)                                             \
-        if (ks_ == 0 && tid < TR) {                                                                             \
-            const uint32_t par_ = tile_ % 3;                                                                    \
-            sAlpha[par_ * TR + tid] = r_alpha;                                                                  \
-            sBeta[par_ * TR + tid] = r_beta;                                                                    \
-            unsigned long long bal_ = __ballot(r_valid); /* TR is a multiple of 64: whole waves */              \
-            if (lane == 0) {                                                                                    \
-                sValid[par_ * (TR / 32) + 2 * w] = (uint32_t)bal_;                                              \
-                sValid[par_ * (TR / 32) + 2 * w + 1] = (uint32_t)(bal_ >> 32);                                  \
-            }                                                                                                   \
-        }                                                                                                       \
+#define VDB_SC(TILE, KSI)                                                                              \
+    if ((KSI) == 0) { /* wave-uniform; LDS stores only */                                              \
+        const uint32_t par_ = (TILE) % 3;                                                              \
+        const bool ok_ = r_inrange && ((r_mask >> r_bit) & 1u);                                        \
+        sAlpha[par_ * TR + (tid % TR)] = r_alpha;                                                      \
+        sBeta[par_ * TR + (tid % TR)] = ok_ ? r_beta : __uint_as_float(0x7f800000u); /* +inf never passes */ \
+        unsigned long long bal_ = __ballot(ok_);                                                       \
+        if (w < TR / 64 && lane == 0) {                                                                \
+            sValid[par_ * (TR / 32) + 2 * w] = (uint32_t)bal_;                                         \
+            sValid[par_ * (TR / 32) + 2 * w + 1] = (uint32_t)(bal_ >> 32);                             \
+        }                                                                                              \
     }
 
     f32x16 acc[MT];
@@ -172,40 +174,83 @@ __global__ __launch_bounds__(512, 2) void fused_score_filter_kernel(FusedParams 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    // ---- prologue
-    ISSUE_LOADS(0u);
-    WRITE_LDS(0u);
+    // ---- prologue: stage 0 -> LDS image 0, stage 1 -> registers (in flight)
+    VDB_LA(0, ra0, 0u, 0u) VDB_LA(1, ra1, 0u, 0u) VDB_LA(2, ra2, 0u, 0u) VDB_LA(3, ra3, 0u, 0u)
+    VDB_LB(0, rb0, 0u) VDB_LB(1, rb1, 0u) VDB_LB(2, rb2, 0u) VDB_LB(3, rb3, 0u)
+    VDB_LC(0u)
+    VDB_SA(0, ra0, 0u) VDB_SA(1, ra1, 0u) VDB_SA(2, ra2, 0u) VDB_SA(3, ra3, 0u)
+    VDB_SB(0, rb0, 0u) VDB_SB(1, rb1, 0u) VDB_SB(2, rb2, 0u) VDB_SB(3, rb3, 0u)
+    VDB_SC(0u, 0u)
+    uint32_t tile = 0, ks = 0;             // stage being computed
+    uint32_t tile1 = 0, ks1 = 1;           // stage st+1 (in the staging registers)
+    if (ks1 == KS) { ks1 = 0; tile1 = 1; }
+    if (total > 1) {
+        VDB_LA(0, ra0, tile1, ks1) VDB_LA(1, ra1, tile1, ks1) VDB_LA(2, ra2, tile1, ks1) VDB_LA(3, ra3, tile1, ks1)
+        VDB_LB(0, rb0, ks1) VDB_LB(1, rb1, ks1) VDB_LB(2, rb2, ks1) VDB_LB(3, rb3, ks1)
+        VDB_LC(tile1)
+    }
     __syncthreads();
 
-    for (uint32_t st = 0; st < total; ++st) {
-        const uint32_t tile = st / KS, ks = st - tile * KS;
+    // One K stage.  PARTIAL selects the code for a tile with fewer than TR valid rows (only the last
+    // tile of a row range); it runs in a separate loop so that the hot loop has one straight-line
+    // MFMA block (a shared block with a branch made the compiler copy all accumulators every stage).
+    auto run_stage = [&](uint32_t st, auto partial_tag) {
+        constexpr bool PARTIAL = decltype(partial_tag)::value;
         const uint32_t tr0 = r0 + tile * TR;
-        const uint32_t mt_valid = (r1 - tr0 + 31) >> 5;                 // valid 32-row blocks left (may exceed the tile)
-        const bool more = st + 1 < total;
-        if (more) ISSUE_LOADS(st + 1);
+        const uint32_t mt_valid = PARTIAL ? ((r1 - tr0 + 31) >> 5) : (uint32_t)(TR / 32);
+        (void)st;
+        uint32_t tile2 = tile1, ks2 = ks1 + 1;
+        if (ks2 == KS) { ks2 = 0; ++tile2; }
+        const uint32_t nbuf = (st + 1) & 1;
+        // staging step I: write one register of stage st+1 to the other LDS image, then refill it
+        // (past the end of the range the stores go to an LDS image nobody reads and the loads are
+        //  clamped to valid rows: keeping them unconditional is what lets the waits be counted)
+#define VDB_STEP_A(I, REG) { VDB_SA(I, REG, nbuf) VDB_LA(I, REG, tile2, ks2) }
+#define VDB_STEP_B(I, REG) { VDB_SB(I, REG, nbuf) VDB_LB(I, REG, ks2) }
+#define VDB_STEP_C() { VDB_SC(tile1, ks1) VDB_LC(tile2) }
 
-        // ---- MFMAs of this stage
         const char* sa = smem + (st & 1) * C::STAGE_BYTES;
         const char* bptr = sa + C::A_BYTES + (qt * 32 + c) * ROWB + h * 16;
         const char* aptr = sa + (rp * MT * 32 + c) * ROWB + h * 16;
-        if (mt_valid >= TR / 32) {
+        if (p.ablate & 1u) {
+            VDB_STEP_C()
+            VDB_STEP_A(0, ra0) VDB_STEP_A(1, ra1) VDB_STEP_A(2, ra2) VDB_STEP_A(3, ra3)
+            VDB_STEP_B(0, rb0) VDB_STEP_B(1, rb1) VDB_STEP_B(2, rb2) VDB_STEP_B(3, rb3)
+        } else if constexpr (!PARTIAL) {
+            // fragments double-buffered across the 4 K groups: group g+1 is read while g's MFMAs run
+            float4 fbA, fbB, faA[MT], faB[MT];
+            fbA = *reinterpret_cast<const float4*>(bptr);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 fb = *reinterpret_cast<const float4*>(bptr + g * 32);
-                float4 fa[MT];
-#pragma unroll
-                for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const float4*>(aptr + i * 32 * ROWB + g * 32);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) acc[i] = VDB_MFMA(fa[i].x, fb.x, acc[i]);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) acc[i] = VDB_MFMA(fa[i].y, fb.y, acc[i]);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) acc[i] = VDB_MFMA(fa[i].z, fb.z, acc[i]);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) acc[i] = VDB_MFMA(fa[i].w, fb.w, acc[i]);
-            }
+            for (int i = 0; i < MT; ++i) faA[i] = *reinterpret_cast<const float4*>(aptr + i * 32 * ROWB);
+#define VDB_GROUP(G, FB, FA, FBN, FAN, S0, S1)                                                         \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i] = VDB_MFMA(FA[i].x, FB.x, acc[i]);       \
+        S0;                                                                                            \
+        VDB_PIN();                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i] = VDB_MFMA(FA[i].y, FB.y, acc[i]);       \
+        S1;                                                                                            \
+        if constexpr ((G) < 3) {                                                                       \
+            FBN = *reinterpret_cast<const float4*>(bptr + ((G) + 1) * 32);                             \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                             \
+                FAN[i] = *reinterpret_cast<const float4*>(aptr + i * 32 * ROWB + ((G) + 1) * 32);      \
+        }                                                                                              \
+        VDB_PIN();                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i] = VDB_MFMA(FA[i].z, FB.z, acc[i]);       \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i] = VDB_MFMA(FA[i].w, FB.w, acc[i]);       \
+        VDB_PIN();                                                                                     \
+    }
+            // the row-constant step goes FIRST: its loads are loop-carried scalars that hipcc copies at the
+            // loop latch, so they need the rest of the stage to land before that copy's wait
+            VDB_GROUP(0, fbA, faA, fbB, faB, VDB_STEP_C() VDB_STEP_A(0, ra0), VDB_STEP_A(1, ra1))
+            VDB_GROUP(1, fbB, faB, fbA, faA, VDB_STEP_A(2, ra2), VDB_STEP_A(3, ra3))
+            VDB_GROUP(2, fbA, faA, fbB, faB, VDB_STEP_B(0, rb0), VDB_STEP_B(1, rb1))
+            VDB_GROUP(3, fbB, faB, fbA, faA, VDB_STEP_B(2, rb2), VDB_STEP_B(3, rb3))
+#undef VDB_GROUP
         } else {
-            // partial last tile: only the valid 32-row blocks (wave-uniform predicate)
+            VDB_STEP_C()
+            VDB_STEP_A(0, ra0) VDB_STEP_A(1, ra1) VDB_STEP_A(2, ra2) VDB_STEP_A(3, ra3)
+            VDB_STEP_B(0, rb0) VDB_STEP_B(1, rb1) VDB_STEP_B(2, rb2) VDB_STEP_B(3, rb3)
+            // only the valid 32-row blocks (wave-uniform predicate)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 fb = *reinterpret_cast<const float4*>(bptr + g * 32);
@@ -221,64 +266,41 @@ __global__ __launch_bounds__(512, 2) void fused_score_filter_kernel(FusedParams 
                 }
             }
         }
+#undef VDB_STEP_A
+#undef VDB_STEP_B
+#undef VDB_STEP_C
+        if (!(p.ablate & 4u)) __syncthreads();
 
-        if (more) WRITE_LDS(st + 1);
-        __syncthreads();
-
-        if (ks == KS - 1) {
-            // ---- epilogue of this tile: score, inclusive threshold, rare append
+        if (ks == KS - 1 && !(p.ablate & 8u)) {
+            // ---- epilogue of this tile: ranking score, inclusive threshold, append the rare survivors
+            // to this lane's private sub-pool (no atomics, no cross-lane traffic)
             const uint32_t par = tile % 3;
             const float* al = sAlpha + par * TR + 4 * h;
             const float* be = sBeta + par * TR + 4 * h;
-            uint32_t cnt = 0;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const uint32_t mtg = rp * MT + i;
-                if (mtg < mt_valid) {
+                if (!PARTIAL || mtg < mt_valid) {
+                    const uint32_t vbits = sValid[par * (TR / 32) + mtg] >> (4 * h);
+                    const uint32_t rowb = tr0 + mtg * 32 + 4 * h;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float4 a4 = *reinterpret_cast<const float4*>(al + mtg * 32 + 8 * j);
                         const float4 b4 = *reinterpret_cast<const float4*>(be + mtg * 32 + 8 * j);
-                        cnt += !(fmaf(acc[i][4 * j + 0], a4.x, b4.x) > thrq);
-                        cnt += !(fmaf(acc[i][4 * j + 1], a4.y, b4.y) > thrq);
-                        cnt += !(fmaf(acc[i][4 * j + 2], a4.z, b4.z) > thrq);
-                        cnt += !(fmaf(acc[i][4 * j + 3], a4.w, b4.w) > thrq);
-                    }
-                }
-            }
-            const uint32_t other = __shfl_xor(cnt, 32);
-            const uint32_t tot = cnt + other;
-            if (__ballot(tot != 0) != 0ull) {
-                uint32_t base = 0;
-                if (h == 0 && tot) base = atomicAdd(&p.pool_cnt[q], tot);
-                base = __shfl(base, c);
-                uint32_t off = base + (h ? other : 0u);
-                uint64_t* pool = p.pool + (size_t)q * p.capq;
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const uint32_t mtg = rp * MT + i;
-                    if (mtg < mt_valid) {
-                        const uint32_t vbits = sValid[par * (TR / 32) + mtg] >> (4 * h);
-                        const uint32_t rowb = tr0 + mtg * 32 + 4 * h;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float4 a4 = *reinterpret_cast<const float4*>(al + mtg * 32 + 8 * j);
-                            const float4 b4 = *reinterpret_cast<const float4*>(be + mtg * 32 + 8 * j);
 #define VDB_PUSH(E, AC, BC)                                                                        \
     {                                                                                              \
         const float sc_ = fmaf(acc[i][4 * j + (E)], (AC), (BC));                                   \
         if (!(sc_ > thrq)) {                                                                       \
             const bool ok_ = (vbits >> (8 * j + (E))) & 1u;                                        \
-            if (off < p.capq) pool[off] = ok_ ? make_key(sc_, rowb + 8 * j + (E)) : EMPTY_KEY;     \
-            ++off;                                                                                 \
+            if (pcnt < p.capl) mypool[pcnt] = ok_ ? make_key(sc_, rowb + 8 * j + (E)) : EMPTY_KEY; \
+            ++pcnt;                                                                                \
         }                                                                                          \
     }
-                            VDB_PUSH(0, a4.x, b4.x)
-                            VDB_PUSH(1, a4.y, b4.y)
-                            VDB_PUSH(2, a4.z, b4.z)
-                            VDB_PUSH(3, a4.w, b4.w)
+                        VDB_PUSH(0, a4.x, b4.x)
+                        VDB_PUSH(1, a4.y, b4.y)
+                        VDB_PUSH(2, a4.z, b4.z)
+                        VDB_PUSH(3, a4.w, b4.w)
 #undef VDB_PUSH
-                        }
                     }
                 }
             }
@@ -287,24 +309,38 @@ __global__ __launch_bounds__(512, 2) void fused_score_filter_kernel(FusedParams 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
         }
-    }
-#undef ISSUE_LOADS
-#undef WRITE_LDS
+        tile = tile1; ks = ks1;
+        tile1 = tile2; ks1 = ks2;
+    };
+
+    const uint32_t full_tiles = (r1 - r0) / TR;                         // tiles with all TR rows valid
+    const uint32_t full_stages = full_tiles * KS;
+    uint32_t st = 0;
+    for (; st < full_stages; ++st) run_stage(st, std::false_type{});
+    for (; st < total; ++st) run_stage(st, std::true_type{});
+    p.pool_cnt[sub] = pcnt;                                             // may exceed capl: the select flags it
 #undef VDB_LA
 #undef VDB_LB
+#undef VDB_LC
 #undef VDB_SA
 #undef VDB_SB
+#undef VDB_SC
 }
 
+// nqt = 32-query tiles per workgroup actually needed (1..4); n_super = workgroups along the query axis
 void launch_fused(const FusedParams& p, int nqt, uint32_t n_super, hipStream_t s) {
-    dim3 grid(p.n_wg, n_super), block(512);
+    dim3 grid(p.n_wg, n_super);
     size_t lds = fused_lds_bytes(nqt);
     switch (nqt) {
-    case 1: hipLaunchKernelGGL((fused_score_filter_kernel<1, 1>), grid, block, lds, s, p); break;
-    case 2: hipLaunchKernelGGL((fused_score_filter_kernel<2, 2>), grid, block, lds, s, p); break;
-    case 4: hipLaunchKernelGGL((fused_score_filter_kernel<4, 4>), grid, block, lds, s, p); break;
-    default: hipLaunchKernelGGL((fused_score_filter_kernel<8, 4>), grid, block, lds, s, p); break;
+    case 1: hipLaunchKernelGGL((fused_score_filter_kernel<1, 1, 4>), grid, dim3(256), lds, s, p); break;
+    case 2: hipLaunchKernelGGL((fused_score_filter_kernel<2, 2, 4>), grid, dim3(256), lds, s, p); break;
+    default: hipLaunchKernelGGL((fused_score_filter_kernel<4, 4, 4>), grid, dim3(256), lds, s, p); break;
     }
+}
+// sub-pools per query for a launch with n_wg row ranges: [n_wg][RP][2]
+uint32_t fused_subpools_per_query(int nqt, uint32_t n_wg) {
+    int rp = nqt == 1 ? CfgQ32::RP : nqt == 2 ? CfgQ64::RP : CfgQ128::RP;
+    return n_wg * rp * 2;
 }
 
 }  // namespace vdb

@@ -118,7 +118,7 @@ struct vdb_flat_index {
     // search workspace
     DevBuf<float> w_qp, w_qnorm, w_thr, w_qin, w_outd;
     DevBuf<uint64_t> w_dense, w_samp, w_pool, w_cand, w_exact, w_exsel, w_mask_ids, w_outi;
-    DevBuf<uint32_t> w_cnt, w_rowmask, w_flags, w_outc;
+    DevBuf<uint32_t> w_cnt, w_rowmask, w_flags, w_outc, w_subcnt;
     uint32_t* h_flags = nullptr; size_t h_flags_n = 0;
     uint64_t stats[8] = {0};
     bool profile = false; hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -482,16 +482,18 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
     const bool small = n <= SMALL_N;
     uint32_t S = small ? n : std::min<uint32_t>(16384u, std::max<uint32_t>(2048u, pow2_ceil(n / 256u)));
     if (const char* e = getenv("VDB_SAMPLE")) { if (!small) S = std::min<uint32_t>(n, std::max(64, atoi(e))); }
-    uint64_t expect = small ? 0 : (uint64_t)n * kp / S;
-    uint32_t capq = small ? 0 : std::min<uint32_t>(1u << 20, pow2_ceil(4 * expect + 1024));
+    // candidate pools: one private sub-pool per (query, row range, row part, lane half) of the fused kernel
+    const uint32_t capl = 64;
+    // sub-pools in one pass = queries * row ranges * row parts * 2 = 512 * n_cu for every kernel shape
+    const size_t pass_subs = 512u * (size_t)ix->n_cu;
     if ((rc = ix->w_dense.ensure((size_t)SUPER * S))) return rc;
     if ((rc = ix->w_cand.ensure((size_t)SUPER * kp))) return rc;
     if (!small) {
         if ((rc = ix->w_samp.ensure((size_t)SUPER * kp))) return rc;
-        if ((rc = ix->w_pool.ensure((size_t)SUPER * capq))) return rc;
+        if ((rc = ix->w_pool.ensure(pass_subs * capl))) return rc;
+        if ((rc = ix->w_subcnt.ensure(pass_subs))) return rc;
     }
     uint32_t* d_cnt_a = ix->w_cnt.p;               // sample select counts
-    uint32_t* d_pool_cnt = ix->w_cnt.p + SUPER;    // pool fill
     uint32_t* d_cand_cnt = ix->w_cnt.p + 2 * SUPER;
     ix->stats[4] = S;
     const float eps = eps_coef(ix);
@@ -499,7 +501,9 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
     for (uint32_t q0 = 0; q0 < nq32; q0 += SUPER) {
         const uint32_t nb = std::min(SUPER, nq32 - q0);
         const uint32_t tiles = (nb + 31) / 32;
-        const int nqt = tiles > 4 ? 8 : tiles > 2 ? 4 : tiles > 1 ? 2 : 1;
+        // fused-kernel shape: 32 / 64 / 128 queries per workgroup; 2 workgroups per CU in flight
+        const int nqt = tiles > 2 ? 4 : (int)tiles;
+        const uint32_t n_super = (tiles + nqt - 1) / nqt;          // workgroups along the query axis (1 or 2)
         const float* qp0 = ix->w_qp.p + (size_t)q0 * ld;
 
         vdb::DenseParams dp{ix->d_rows, ld, n, qp0, round_up(nb, 32), ix->d_alpha, ix->d_beta, d_rowmask, S,
@@ -516,12 +520,14 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
             // thresholds: the sample's kp-th score (padding queries were given -inf by query_prep)
             sp.out_keys = ix->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->w_thr.p + q0; sp.ovf = nullptr;
             vdb::launch_select(sp, nb, s);
-            HIP_TRY(hipMemsetAsync(d_pool_cnt, 0, SUPER * 4, s));
-            vdb::FusedParams fp{ix->d_rows, ld, n, ix->w_qp.p, q0, ix->d_alpha, ix->d_beta, d_rowmask,
-                                ix->w_thr.p, ix->w_pool.p - (size_t)q0 * capq, d_pool_cnt - q0, capq,
-                                (uint32_t)std::min<uint32_t>((uint32_t)ix->n_cu, (n + 31) / 32)};
+            const uint32_t n_wg = std::min<uint32_t>(2u * (uint32_t)ix->n_cu / n_super, (n + 31) / 32);
+            const uint32_t n_sub = vdb::fused_subpools_per_query(nqt, n_wg);
+            vdb::FusedParams fp{ix->d_rows, ld, n, ix->w_qp.p, q0, ix->d_alpha, ix->d_beta, d_rowmask ? d_rowmask : ix->d_live,
+                                ix->w_thr.p, ix->w_pool.p - (size_t)q0 * n_sub * capl,
+                                ix->w_subcnt.p - (size_t)q0 * n_sub, capl, n_wg,
+                                getenv("VDB_FUSED_ABLATE") ? (uint32_t)atoi(getenv("VDB_FUSED_ABLATE")) : 0u};
             if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
-            vdb::launch_fused(fp, nqt, 1, s);
+            vdb::launch_fused(fp, nqt, n_super, s);
             if (ix->profile) {
                 // one super-tile per event pair: wait here so the pair can be reused (profiling mode only)
                 HIP_TRY(hipEventRecord(ix->ev1, s));
@@ -532,7 +538,8 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
             }
             ix->stats[3] += n;
             vdb::SelectParams mp{};
-            mp.keys = ix->w_pool.p; mp.stride = capq; mp.counts = d_pool_cnt; mp.n_fixed = 0; mp.cap = capq;
+            mp.keys = ix->w_pool.p; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
+            mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl;
             mp.kk = kp; mp.out_keys = ix->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
             mp.out_thr = nullptr; mp.ovf = d_ovf + q0;
             vdb::launch_select(mp, nb, s);
@@ -636,7 +643,7 @@ void vdb_flat_destroy(vdb_flat_index* ix) {
     ix->w_qp.release(); ix->w_qnorm.release(); ix->w_thr.release(); ix->w_qin.release(); ix->w_outd.release();
     ix->w_dense.release(); ix->w_samp.release(); ix->w_pool.release(); ix->w_cand.release(); ix->w_exact.release();
     ix->w_exsel.release(); ix->w_mask_ids.release(); ix->w_outi.release();
-    ix->w_cnt.release(); ix->w_rowmask.release(); ix->w_flags.release(); ix->w_outc.release();
+    ix->w_cnt.release(); ix->w_subcnt.release(); ix->w_rowmask.release(); ix->w_flags.release(); ix->w_outc.release();
     if (ix->h_flags) (void)hipHostFree(ix->h_flags);
     if (ix->ev0) { (void)hipEventDestroy(ix->ev0); (void)hipEventDestroy(ix->ev1); }
     (void)hipStreamDestroy(ix->stream);
