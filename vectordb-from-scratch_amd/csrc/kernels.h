@@ -136,6 +136,7 @@ struct RerankParams {
     uint64_t* out_ids; float* out_dists; uint32_t* out_counts; uint32_t out_stride;
     uint32_t* cert;                                    // [nq]: 1 = certified exact
     uint32_t* status;
+    uint32_t lds_row_stride, lds_chunk;                // filled by launch_rerank
 };
 void launch_rerank(const RerankParams& p, uint32_t nq, hipStream_t s);
 

@@ -17,16 +17,23 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // sqrt uses __builtin_sqrtf (correctly rounded expansion); HIP's __fsqrt_rn lowers to a bare
 // v_sqrt_f32 (1 ulp) on gfx950 and is NOT usable for bit parity.
 // ---------------------------------------------------------------------------------------------
+// Each fold loads 16 elements (4 x 16 bytes) before it consumes them, so the loads of a block are in
+// flight together while the adds stay one strictly sequential chain.
 __device__ __forceinline__ float fold_sq(const float* __restrict__ x, uint32_t d) {
     // vector.rs:35-37   sum_i x_i*x_i
     float s = 0.0f;
     uint32_t i = 0;
-    for (; i + 4 <= d; i += 4) {
-        float4 v = *reinterpret_cast<const float4*>(x + i);
-        s = __fadd_rn(s, __fmul_rn(v.x, v.x));
-        s = __fadd_rn(s, __fmul_rn(v.y, v.y));
-        s = __fadd_rn(s, __fmul_rn(v.z, v.z));
-        s = __fadd_rn(s, __fmul_rn(v.w, v.w));
+    for (; i + 16 <= d; i += 16) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + i + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s = __fadd_rn(s, __fmul_rn(v[u].x, v[u].x));
+            s = __fadd_rn(s, __fmul_rn(v[u].y, v[u].y));
+            s = __fadd_rn(s, __fmul_rn(v[u].z, v[u].z));
+            s = __fadd_rn(s, __fmul_rn(v[u].w, v[u].w));
+        }
     }
     for (; i < d; ++i) s = __fadd_rn(s, __fmul_rn(x[i], x[i]));
     return s;
@@ -36,13 +43,20 @@ __device__ __forceinline__ float fold_dot(const float* __restrict__ q, const flo
     // distance.rs:67-73   sum_i a_i*b_i
     float s = 0.0f;
     uint32_t i = 0;
-    for (; i + 4 <= d; i += 4) {
-        float4 a = *reinterpret_cast<const float4*>(q + i);
-        float4 b = *reinterpret_cast<const float4*>(x + i);
-        s = __fadd_rn(s, __fmul_rn(a.x, b.x));
-        s = __fadd_rn(s, __fmul_rn(a.y, b.y));
-        s = __fadd_rn(s, __fmul_rn(a.z, b.z));
-        s = __fadd_rn(s, __fmul_rn(a.w, b.w));
+    for (; i + 16 <= d; i += 16) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const float4*>(q + i + 4 * u);
+            b[u] = *reinterpret_cast<const float4*>(x + i + 4 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s = __fadd_rn(s, __fmul_rn(a[u].x, b[u].x));
+            s = __fadd_rn(s, __fmul_rn(a[u].y, b[u].y));
+            s = __fadd_rn(s, __fmul_rn(a[u].z, b[u].z));
+            s = __fadd_rn(s, __fmul_rn(a[u].w, b[u].w));
+        }
     }
     for (; i < d; ++i) s = __fadd_rn(s, __fmul_rn(q[i], x[i]));
     return s;
@@ -52,14 +66,21 @@ __device__ __forceinline__ float fold_sqdiff(const float* __restrict__ q, const 
     // distance.rs:37-44   sum_i (a_i-b_i)^2   (powi(2) == t*t)
     float s = 0.0f;
     uint32_t i = 0;
-    for (; i + 4 <= d; i += 4) {
-        float4 a = *reinterpret_cast<const float4*>(q + i);
-        float4 b = *reinterpret_cast<const float4*>(x + i);
-        float t;
-        t = __fsub_rn(a.x, b.x); s = __fadd_rn(s, __fmul_rn(t, t));
-        t = __fsub_rn(a.y, b.y); s = __fadd_rn(s, __fmul_rn(t, t));
-        t = __fsub_rn(a.z, b.z); s = __fadd_rn(s, __fmul_rn(t, t));
-        t = __fsub_rn(a.w, b.w); s = __fadd_rn(s, __fmul_rn(t, t));
+    for (; i + 16 <= d; i += 16) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const float4*>(q + i + 4 * u);
+            b[u] = *reinterpret_cast<const float4*>(x + i + 4 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float t;
+            t = __fsub_rn(a[u].x, b[u].x); s = __fadd_rn(s, __fmul_rn(t, t));
+            t = __fsub_rn(a[u].y, b[u].y); s = __fadd_rn(s, __fmul_rn(t, t));
+            t = __fsub_rn(a[u].z, b[u].z); s = __fadd_rn(s, __fmul_rn(t, t));
+            t = __fsub_rn(a[u].w, b[u].w); s = __fadd_rn(s, __fmul_rn(t, t));
+        }
     }
     for (; i < d; ++i) { float t = __fsub_rn(q[i], x[i]); s = __fadd_rn(s, __fmul_rn(t, t)); }
     return s;
@@ -155,16 +176,20 @@ void launch_build_rowmask(const uint64_t* row_ids, const uint32_t* livemask, con
 // and compute each query's exact-order norm (one wave per query row; lane 0 folds).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sQrow[];      // [ld]
     uint32_t q = blockIdx.x;
     float* dst = p.qp + (size_t)q * p.ld;
     const float* src = p.q_in + (size_t)q * p.dim;
-    for (uint32_t i = threadIdx.x; i < p.ld; i += blockDim.x)
-        dst[i] = (q < p.nq && i < p.dim) ? src[i] : 0.0f;
+    for (uint32_t i = threadIdx.x; i < p.ld; i += blockDim.x) {
+        float v = (q < p.nq && i < p.dim) ? src[i] : 0.0f;
+        dst[i] = v;
+        sQrow[i] = v;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         float n = 0.0f;
         if (q < p.nq) {
-            n = __builtin_sqrtf(fold_sq(dst, p.dim));
+            n = __builtin_sqrtf(fold_sq(sQrow, p.dim));                // sequential fold, from LDS
             if (p.metric == COSINE && n == 0.0f) atomicOr(p.status, ST_ZERO_QUERY);
         }
         p.qnorm[q] = n;
@@ -172,7 +197,7 @@ __global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepParams p) {
     }
 }
 void launch_query_prep(const QueryPrepParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(query_prep_kernel, dim3(p.nq_pad), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(query_prep_kernel, dim3(p.nq_pad), dim3(256), (size_t)p.ld * sizeof(float), s, p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -201,16 +226,36 @@ __global__ __launch_bounds__(256) void dense_scores_kernel(DenseParams p) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    const uint32_t ngroups = p.ld / 8;
-#pragma unroll 4
-    for (uint32_t g = 0; g < ngroups; ++g) {
-        float4 a = *reinterpret_cast<const float4*>(ap + 8 * g);
-        float4 b = *reinterpret_cast<const float4*>(bp + 8 * g);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    // ld is a multiple of 32, so the K groups of 8 come in blocks of 4.  Only ~1 wave per SIMD is
+    // in flight here, so each wave keeps two blocks of operand loads ahead of its MFMAs.
+    const uint32_t nblocks = p.ld / 32;
+    float4 a0[4], b0[4], a1[4], b1[4], a2[4], b2[4];
+#define VDB_DLOAD(A, B, BLK)                                                                  \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                           \
+        A[u] = *reinterpret_cast<const float4*>(ap + 32 * (BLK) + 8 * u);                     \
+        B[u] = *reinterpret_cast<const float4*>(bp + 32 * (BLK) + 8 * u);                     \
     }
+#define VDB_DMFMA(A, B)                                                                       \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                           \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u].x, B[u].x, acc, 0, 0, 0);             \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u].y, B[u].y, acc, 0, 0, 0);             \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u].z, B[u].z, acc, 0, 0, 0);             \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[u].w, B[u].w, acc, 0, 0, 0);             \
+    }
+    VDB_DLOAD(a0, b0, 0u)
+    if (nblocks > 1) { VDB_DLOAD(a1, b1, 1u) }
+    for (uint32_t blk = 0; blk < nblocks; blk += 3) {
+        if (blk + 2 < nblocks) { VDB_DLOAD(a2, b2, blk + 2) }
+        VDB_DMFMA(a0, b0)
+        if (blk + 1 >= nblocks) break;
+        if (blk + 3 < nblocks) { VDB_DLOAD(a0, b0, blk + 3) }
+        VDB_DMFMA(a1, b1)
+        if (blk + 2 >= nblocks) break;
+        if (blk + 4 < nblocks) { VDB_DLOAD(a1, b1, blk + 4) }
+        VDB_DMFMA(a2, b2)
+    }
+#undef VDB_DLOAD
+#undef VDB_DMFMA
     // C/D layout: column (query) = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const uint32_t q = blockIdx.y * 32 + c;
     uint64_t* out = p.keys + (size_t)q * p.key_stride;
@@ -238,13 +283,14 @@ void launch_dense_scores(const DenseParams& p, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t SEL_LDS_KEYS = 16384;  // keys cached in LDS when n fits (128 KB)
 constexpr uint32_t SEL_MAX_KK = 2048;
+constexpr uint32_t SEL_THREADS = 1024;   // 16 waves per query: the passes are latency-bound
 
-__global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
     extern __shared__ __attribute__((aligned(16))) uint64_t sdyn[];
     uint64_t* sKeys = sdyn;                       // [SEL_LDS_KEYS]
     uint64_t* sOut = sdyn + SEL_LDS_KEYS;         // [SEL_MAX_KK]
     __shared__ uint32_t sHist[256];
-    __shared__ uint32_t sDigit, sRemain, sOutCnt, sValid, sN;
+    __shared__ uint32_t sDigit, sRemain, sBucket, sOutCnt, sValid, sN;
 
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const uint64_t* keys = p.keys + (size_t)q * p.stride;
@@ -256,18 +302,41 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
     __syncthreads();
     uint32_t myvalid = 0;
     if (p.n_sub) {
-        // gather the query's private sub-pools (written by the fused kernel) into LDS
+        // gather the query's private sub-pools (written by the fused kernel) into LDS.  Counts are
+        // staged in LDS first; then each wave takes 4 sub-pools per iteration, lane j reads slot j of
+        // each (four independent coalesced 512-byte loads in flight), and survivors are compacted with
+        // one LDS atomic per sub-pool.  capl is 64 (one slot per lane).
         const uint32_t* sc = p.sub_counts + (size_t)q * p.n_sub;
         const uint64_t* base = p.keys + (size_t)q * p.n_sub * p.capl;
         bool over = false;
-        for (uint32_t s2 = tid; s2 < p.n_sub; s2 += 256) {
-            uint32_t c = sc[s2];
+        uint32_t* sCnt = reinterpret_cast<uint32_t*>(sOut);      // sOut is not in use yet: room for 4096 counts
+        for (uint32_t i = tid; i < p.n_sub; i += SEL_THREADS) {
+            uint32_t c = sc[i];
             if (c > p.capl) { c = p.capl; over = true; }
-            for (uint32_t j = 0; j < c; ++j) {
-                uint64_t k = base[(size_t)s2 * p.capl + j];
-                uint32_t slot = atomicAdd(&sN, 1u);
-                if (slot < SEL_LDS_KEYS) { sKeys[slot] = k; myvalid += (k != EMPTY_KEY); }
-                else over = true;
+            sCnt[i] = c;
+        }
+        __syncthreads();
+        const uint32_t wv = tid >> 6;
+        for (uint32_t s0 = wv * 4; s0 < p.n_sub; s0 += 4 * (SEL_THREADS / 64)) {
+            uint32_t c[4];
+            uint64_t k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                c[u] = (s0 + u < p.n_sub) ? sCnt[s0 + u] : 0u;
+                k[u] = (lane < c[u]) ? base[(size_t)(s0 + u) * p.capl + lane] : EMPTY_KEY;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (c[u] == 0) continue;                      // wave-uniform
+                const bool have = lane < c[u];
+                unsigned long long m = __ballot(have);
+                uint32_t pos = 0;
+                if (lane == 0) pos = atomicAdd(&sN, (uint32_t)__popcll(m));
+                pos = __shfl(pos, 0) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (have) {
+                    if (pos < SEL_LDS_KEYS) { sKeys[pos] = k[u]; myvalid += (k[u] != EMPTY_KEY); }
+                    else over = true;
+                }
             }
         }
         if (over && p.ovf) p.ovf[q] = 1u;
@@ -281,7 +350,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
             n = c;
         }
         cached = n <= SEL_LDS_KEYS;
-        for (uint32_t i = tid; i < n; i += 256) {
+        for (uint32_t i = tid; i < n; i += SEL_THREADS) {
             uint64_t k = keys[i];
             if (has_lo && k <= lo) k = EMPTY_KEY;          // already emitted by an earlier chunk
             if (cached) sKeys[i] = k;
@@ -295,22 +364,39 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
     const uint32_t kk = nvalid < p.kk ? nvalid : p.kk;
     uint64_t* out = p.out_keys + (size_t)q * p.out_stride;
     if (kk == 0) {
-        for (uint32_t i = tid; i < p.kk; i += 256) out[i] = EMPTY_KEY;
+        for (uint32_t i = tid; i < p.kk; i += SEL_THREADS) out[i] = EMPTY_KEY;
         if (tid == 0) { p.out_cnt[q] = 0; if (p.out_thr) p.out_thr[q] = __uint_as_float(0x7f800000u); }
         return;
     }
     // ---- find the kk-th smallest key
     uint64_t prefix = 0;
     uint32_t remain = kk;
+    uint32_t inbucket = nvalid;          // keys still matching the prefix
     for (int b = 7; b >= 0; --b) {
-        sHist[tid] = 0;
+        if (tid < 256) sHist[tid] = 0;
         __syncthreads();
         const int shift = 8 * b;
-        for (uint32_t i = tid; i < n; i += 256) {
+        // Scores are concentrated, so in the first passes nearly every key lands in one or two bins:
+        // aggregate equal digits inside the wave (one LDS atomic per distinct digit) while many keys
+        // still take part; plain atomics once the bucket is small.
+        const bool aggregate = (b == 7) && inbucket > 512;   // top byte: sign and exponent, usually one value
+        for (uint32_t i = tid; i < n; i += SEL_THREADS) {
             uint64_t k = cached ? sKeys[i] : keys[i];
             if (!cached && has_lo && k <= lo) k = EMPTY_KEY;
             bool in = (k != EMPTY_KEY) && (b == 7 || (k >> (shift + 8)) == prefix);
-            if (in) atomicAdd(&sHist[(uint32_t)(k >> shift) & 255u], 1u);
+            uint32_t d = (uint32_t)(k >> shift) & 255u;
+            if (aggregate) {
+                unsigned long long active = __ballot(in);
+                while (active) {
+                    int leader = __ffsll((long long)active) - 1;
+                    uint32_t dl = __shfl(d, leader);
+                    unsigned long long same = __ballot(in && d == dl);
+                    if ((int)lane == leader) atomicAdd(&sHist[dl], (uint32_t)__popcll(same));
+                    active &= ~same;
+                }
+            } else if (in) {
+                atomicAdd(&sHist[d], 1u);
+            }
         }
         __syncthreads();
         if (tid < 64) {
@@ -321,20 +407,22 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
             int first = __ffsll((long long)hit) - 1;
             if ((int)lane == first) {
                 uint32_t r = remain - (incl - sum);
-                uint32_t d = 0;
-                if (r > c0) { r -= c0; d = 1; if (r > c1) { r -= c1; d = 2; if (r > c2) { r -= c2; d = 3; } } }
+                uint32_t d = 0, cd = c0;
+                if (r > c0) { r -= c0; d = 1; cd = c1; if (r > c1) { r -= c1; d = 2; cd = c2; if (r > c2) { r -= c2; d = 3; cd = c3; } } }
                 sDigit = 4 * lane + d;
                 sRemain = r;
+                sBucket = cd;
             }
         }
         __syncthreads();
         prefix = (prefix << 8) | sDigit;
         remain = sRemain;
+        inbucket = sBucket;
         __syncthreads();
     }
     const uint64_t pivot = prefix;
     // ---- collect keys <= pivot (exactly kk of them, keys are distinct)
-    for (uint32_t i = tid; i < n; i += 256) {
+    for (uint32_t i = tid; i < n; i += SEL_THREADS) {
         uint64_t k = cached ? sKeys[i] : keys[i];
         if (!cached && has_lo && k <= lo) k = EMPTY_KEY;
         if (k <= pivot) {     // EMPTY_KEY is the maximum and pivot is a real key, so it never passes
@@ -345,11 +433,11 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
     __syncthreads();
     uint32_t P = 2;
     while (P < kk) P <<= 1;
-    for (uint32_t i = kk + tid; i < P; i += 256) sOut[i] = EMPTY_KEY;
+    for (uint32_t i = kk + tid; i < P; i += SEL_THREADS) sOut[i] = EMPTY_KEY;
     __syncthreads();
     for (uint32_t size = 2; size <= P; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = tid; t < P / 2; t += 256) {
+            for (uint32_t t = tid; t < P / 2; t += SEL_THREADS) {
                 uint32_t lo = 2 * t - (t & (stride - 1));      // index with bit `stride` cleared
                 uint32_t hi2 = lo + stride;
                 bool up = ((lo & size) == 0);
@@ -359,7 +447,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
             __syncthreads();
         }
     }
-    for (uint32_t i = tid; i < p.kk; i += 256) out[i] = i < kk ? sOut[i] : EMPTY_KEY;
+    for (uint32_t i = tid; i < p.kk; i += SEL_THREADS) out[i] = i < kk ? sOut[i] : EMPTY_KEY;
     if (tid == 0) {
         p.out_cnt[q] = kk;
         if (p.out_last) p.out_last[q] = sOut[kk - 1];
@@ -369,7 +457,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelectParams p) {
 }
 void launch_select(const SelectParams& p, uint32_t nq, hipStream_t s) {
     if (!nq) return;
-    hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(256), (SEL_LDS_KEYS + SEL_MAX_KK) * sizeof(uint64_t), s, p);
+    hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(SEL_THREADS), (SEL_LDS_KEYS + SEL_MAX_KK) * sizeof(uint64_t), s, p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -382,32 +470,61 @@ void launch_select(const SelectParams& p, uint32_t nq, hipStream_t s) {
 // excluded row can enter the top k and the result is exact.  Otherwise cert[q] = 0 and
 // the host re-does that query with the exact scan.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void rerank_kernel(RerankParams p) {
+__global__ __launch_bounds__(256) void rerank_kernel(RerankParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sRows[];   // query row + `chunk` candidate rows
     __shared__ uint32_t sDist[128];     // ordered exact distance
     __shared__ uint64_t sId[128];
+    __shared__ uint32_t sRowIdx[128];
     __shared__ uint32_t sAnyNan, sNanKey;
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     const uint32_t cnt = p.cand_cnt[q];
     if (tid == 0) { sAnyNan = 0; sNanKey = 0; }
-    __syncthreads();
-    uint32_t od = 0xffffffffu;
-    uint64_t id = ~0ull;
-    if (tid < cnt) {
-        uint64_t key = p.cand[(size_t)q * p.cand_stride + tid];
-        uint32_t row = (uint32_t)key;
-        if ((uint32_t)(key >> 32) == 0u) sNanKey = 1u;      // approximate score was NaN
-        bool ok = row < p.n_rows && (p.rowmask ? ((p.rowmask[row >> 5] >> (row & 31)) & 1u) : true);
-        if (ok) {
-            float dist = exact_distance(p.metric, p.qp + (size_t)q * p.ld, p.rows + (size_t)row * p.ld, p.dim,
-                                        p.qnorm[q], p.nd[row]);
-            if (dist != dist) sAnyNan = 1u;
-            od = f32_to_ordered(dist);
-            id = p.row_ids[row];
+    if (tid < 128) {
+        uint32_t row = 0xffffffffu;
+        if (tid < cnt) {
+            uint64_t key = p.cand[(size_t)q * p.cand_stride + tid];
+            row = (uint32_t)key;
+            if ((uint32_t)(key >> 32) == 0u) sNanKey = 1u;      // approximate score was NaN (benign race)
+            bool ok = row < p.n_rows && (p.rowmask ? ((p.rowmask[row >> 5] >> (row & 31)) & 1u) : true);
+            if (!ok) row = 0xffffffffu;
         }
+        sRowIdx[tid] = row;
+        sDist[tid] = 0xffffffffu;
+        sId[tid] = ~0ull;
     }
-    sDist[tid] = od;
-    sId[tid] = id;
+    // stage the query and, chunk by chunk, the candidate rows in LDS (coalesced), then ONE thread per
+    // candidate folds in the reference's order; row stride is padded so 16 lanes' b128 reads tile the banks
+    const uint32_t dimp = (p.dim + 3) & ~3u;
+    const uint32_t ldp = p.lds_row_stride;
+    const uint32_t chunk = p.lds_chunk;
+    float* sQ = sRows;
+    float* sR = sRows + ldp;
+    const float* gq = p.qp + (size_t)q * p.ld;                    // zero padded up to ld >= dimp
+    for (uint32_t i = tid * 4; i < dimp; i += 1024) *reinterpret_cast<float4*>(sQ + i) = *reinterpret_cast<const float4*>(gq + i);
     __syncthreads();
+    const uint32_t vec_per_row = dimp / 4;
+    for (uint32_t c0 = 0; c0 < cnt; c0 += chunk) {
+        const uint32_t nthis = (cnt - c0 < chunk) ? cnt - c0 : chunk;
+        for (uint32_t r = tid >> 6; r < nthis; r += 4) {            // one wave per candidate row
+            const uint32_t row = sRowIdx[c0 + r];
+            if (row == 0xffffffffu) continue;
+            const float* src = p.rows + (size_t)row * p.ld;
+            float* dstr = sR + (size_t)r * ldp;
+            for (uint32_t c4 = tid & 63; c4 < vec_per_row; c4 += 64)
+                *reinterpret_cast<float4*>(dstr + 4 * c4) = *reinterpret_cast<const float4*>(src + 4 * c4);
+        }
+        __syncthreads();
+        if (tid < nthis) {
+            uint32_t row = sRowIdx[c0 + tid];
+            if (row != 0xffffffffu) {
+                float dist = exact_distance(p.metric, sQ, sR + (size_t)tid * ldp, p.dim, p.qnorm[q], p.nd[row]);
+                if (dist != dist) sAnyNan = 1u;
+                sDist[c0 + tid] = f32_to_ordered(dist);
+                sId[c0 + tid] = p.row_ids[row];
+            }
+        }
+        __syncthreads();
+    }
     // bitonic sort of 128 (dist, id) pairs, ascending
     for (uint32_t size = 2; size <= 128; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
@@ -426,9 +543,9 @@ __global__ __launch_bounds__(128) void rerank_kernel(RerankParams p) {
     // number of real candidates (ineligible ones sorted to the end with id ~0)
     uint32_t real = 0;
     {
-        unsigned long long b0 = __ballot(sId[tid] != ~0ull);
+        unsigned long long b0 = __ballot(tid < 128 && sId[tid & 127] != ~0ull);
         __shared__ uint32_t sReal[2];
-        if ((tid & 63) == 0) sReal[tid >> 6] = (uint32_t)__popcll(b0);
+        if ((tid & 63) == 0 && tid < 128) sReal[tid >> 6] = (uint32_t)__popcll(b0);
         __syncthreads();
         real = sReal[0] + sReal[1];
     }
@@ -468,7 +585,15 @@ __global__ __launch_bounds__(128) void rerank_kernel(RerankParams p) {
 }
 void launch_rerank(const RerankParams& p, uint32_t nq, hipStream_t s) {
     if (!nq) return;
-    hipLaunchKernelGGL(rerank_kernel, dim3(nq), dim3(128), 0, s, p);
+    // LDS plan: query row + `chunk` candidate rows of padded stride (chunk = largest power of two that fits)
+    RerankParams q = p;
+    uint32_t dimp = (p.dim + 3) & ~3u;
+    q.lds_row_stride = dimp + ((dimp % 8 == 0) ? 4 : 0);
+    uint32_t chunk = 32;
+    while (chunk > 1 && (size_t)(chunk + 1) * q.lds_row_stride * 4 > 150 * 1024) chunk >>= 1;
+    q.lds_chunk = chunk;
+    size_t lds = (size_t)(chunk + 1) * q.lds_row_stride * 4;   // dim <= ~19000 fits with chunk = 1
+    hipLaunchKernelGGL(rerank_kernel, dim3(nq), dim3(256), lds, s, q);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -67,7 +67,10 @@ size_t fused_lds_bytes(int nqt) {
 uint32_t fused_tile_rows(int) { return 128; }
 
 #define VDB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-#define VDB_PIN() __builtin_amdgcn_sched_barrier(0)
+#define VDB_PIN() do { if (VDB_USE_PIN) __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifndef VDB_USE_PIN
+#define VDB_USE_PIN 0
+#endif
 
 template <int NQT, int MT, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void fused_score_filter_kernel(FusedParams p) {

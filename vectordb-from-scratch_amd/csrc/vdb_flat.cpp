@@ -419,6 +419,7 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
             return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
     }
     if (nq > 0x7fffffffull / 2 || k > 0x7fffffffull) return fail(VDB_ERR_INVALID_ARGUMENT, "batch too large");
+    if (ix->dim > 16384) return fail(VDB_ERR_INVALID_ARGUMENT, "dimension %u exceeds the supported 16384", ix->dim);
 
     const uint32_t n = ix->n_uploaded;
     const uint32_t ld = ix->ld;
