@@ -93,12 +93,14 @@ class ShardedSearcher:
         B = ids.shape[0]
         # one gather for each dtype (ids, distances) + counts; status rides in an extra counts slot
         cnt_st = torch.cat([counts.to(torch.int32), torch.tensor([code], dtype=torch.int32, device=counts.device)])
-        g_ids = torch.empty((self.world, B, k), dtype=torch.int64, device=ids.device)
-        g_d = torch.empty((self.world, B, k), dtype=torch.float32, device=ids.device)
-        g_c = torch.empty((self.world, B + 1), dtype=torch.int32, device=ids.device)
+        # outputs are the concatenation along dim 0 (the layout both the RCCL and gloo backends accept)
+        g_ids = torch.empty((self.world * B, k), dtype=torch.int64, device=ids.device)
+        g_d = torch.empty((self.world * B, k), dtype=torch.float32, device=ids.device)
+        g_c = torch.empty((self.world * (B + 1),), dtype=torch.int32, device=ids.device)
         dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=self.group)
         dist.all_gather_into_tensor(g_d, dists.contiguous(), group=self.group)
         dist.all_gather_into_tensor(g_c, cnt_st, group=self.group)
+        g_ids, g_d, g_c = g_ids.view(self.world, B, k), g_d.view(self.world, B, k), g_c.view(self.world, B + 1)
         worst = int(g_c[:, B].max().item())
         if worst:
             if err:
