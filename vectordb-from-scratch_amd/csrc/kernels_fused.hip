@@ -56,11 +56,13 @@ template <int NQT, int MT, int NW> struct FusedCfg {
 using CfgQ128 = FusedCfg<4, 4, 4>;   // headline: 128 queries x 128 rows, 64 accumulator VGPRs per lane, 75 KB LDS
 using CfgQ64 = FusedCfg<2, 2, 4>;
 using CfgQ32 = FusedCfg<1, 1, 4>;
+using CfgQ256 = FusedCfg<8, 4, 8>;   // alternative: ONE 8-wave workgroup per CU, 256 queries share each fetched row tile
 
 size_t fused_lds_bytes(int nqt) {
     switch (nqt) {
     case 1: return CfgQ32::LDS_BYTES;
     case 2: return CfgQ64::LDS_BYTES;
+    case 8: return CfgQ256::LDS_BYTES;
     default: return CfgQ128::LDS_BYTES;
     }
 }
@@ -110,7 +112,6 @@ __global__ __launch_bounds__(NW * 64, 2) void fused_score_filter_kernel(FusedPar
     const uint32_t KS = p.ld / KSTAGE;
     const uint32_t total = ntiles * KS;
     const float thrq = p.thr[q];
-    const float* __restrict__ grow = p.rows;
     const uint32_t ld = p.ld;
     const uint32_t last_row = p.n_rows - 1;
 
@@ -124,26 +125,40 @@ __global__ __launch_bounds__(NW * 64, 2) void fused_score_filter_kernel(FusedPar
     bool r_inrange = false;
     // this thread always stages chunk (tid&7) of rows (tid>>3) + i*NT/8
     const uint32_t srow = tid >> 3, schunk = (tid & 7) * 4;
-    const float* pb0 = p.qp + (size_t)(qwg + srow) * ld + schunk;       // B rows are fixed for the workgroup
-    const size_t pb_step = (size_t)(NT / 8) * ld;
     const uint32_t lds_st = srow * ROWB + (tid & 7) * 16;               // staging write offset inside a tile image
-
-    // load register REG with its float4 of stage (TILE, KSI)
-#define VDB_LA(I, REG, TILE, KSI)                                                                      \
-    if constexpr (C::NA > (I)) {                                                                       \
-        uint32_t row_ = r0 + (TILE) * TR + srow + (I) * (NT / 8);                                      \
-        row_ = row_ > last_row ? last_row : row_; /* in bounds; masked in the epilogue */              \
-        REG = *reinterpret_cast<const float4*>(grow + (size_t)row_ * ld + (KSI) * KSTAGE + schunk);    \
-    }
-#define VDB_LB(I, REG, KSI)                                                                            \
-    if constexpr (C::NB > (I)) { REG = *reinterpret_cast<const float4*>(pb0 + (I) * pb_step + (KSI) * KSTAGE); }
-    // row constants of tile TILE: loaded by every thread, every stage (thread t and t+TR load the same
-    // row; all VMEM in the loop is unconditional so that hipcc can count vmcnt exactly)
-#define VDB_LC(TILE)                                                                                   \
+    // Addresses = wave-uniform base (SGPR pair) + 32-bit per-thread byte offset, so a staging load costs
+    // one v_add.  The per-tile parts (oa*, oc_*) are recomputed only when the fetched tile changes.
+    const char* __restrict__ abase = reinterpret_cast<const char*>(p.rows + (size_t)r0 * ld);
+    const char* __restrict__ bbase = reinterpret_cast<const char*>(p.qp + (size_t)qwg * ld);
+    const uint32_t rows_wg = last_row - r0;                             // clamp: rows past the index stay in bounds
+    const uint32_t ob = (srow * ld + schunk) * 4;                       // B: fixed rows of the workgroup
+    const uint32_t ob_step = (NT / 8) * ld * 4;
+    uint32_t oa0 = 0, oa1 = 0, oa2 = 0, oa3 = 0;                        // A: byte offset of this thread's rows in tile `otile`
+    uint32_t oc_row = 0;                                                // constants: row (relative to r0) of this thread
+#define VDB_TILE_OFFSETS(TILE)                                                                         \
     {                                                                                                  \
-        uint32_t row_ = r0 + (TILE) * TR + (tid % TR);                                                 \
-        r_inrange = row_ < r1;                                                                         \
-        const uint32_t rr_ = r_inrange ? row_ : last_row;                                              \
+        const uint32_t t0_ = (TILE) * TR + srow;                                                       \
+        uint32_t q0_ = t0_, q1_ = t0_ + (NT / 8), q2_ = t0_ + 2 * (NT / 8), q3_ = t0_ + 3 * (NT / 8);  \
+        q0_ = q0_ > rows_wg ? rows_wg : q0_; q1_ = q1_ > rows_wg ? rows_wg : q1_;                      \
+        q2_ = q2_ > rows_wg ? rows_wg : q2_; q3_ = q3_ > rows_wg ? rows_wg : q3_;                      \
+        oa0 = (q0_ * ld + schunk) * 4; oa1 = (q1_ * ld + schunk) * 4;                                  \
+        oa2 = (q2_ * ld + schunk) * 4; oa3 = (q3_ * ld + schunk) * 4;                                  \
+        const uint32_t cr_ = (TILE) * TR + (tid % TR);                                                 \
+        r_inrange_next = r0 + cr_ < r1;                                                                \
+        oc_row = r_inrange_next ? cr_ : rows_wg;                                                       \
+    }
+    bool r_inrange_next = false;
+    // load register REG with its float4 of k-stage KSI of the tile whose offsets are current
+#define VDB_LA(I, REG, OA, KSI)                                                                        \
+    if constexpr (C::NA > (I)) { REG = *reinterpret_cast<const float4*>(abase + ((OA) + (KSI) * (KSTAGE * 4))); }
+#define VDB_LB(I, REG, KSI)                                                                            \
+    if constexpr (C::NB > (I)) { REG = *reinterpret_cast<const float4*>(bbase + (ob + (I) * ob_step + (KSI) * (KSTAGE * 4))); }
+    // row constants of the tile whose offsets are current: loaded by every thread, every stage (thread t
+    // and t+TR load the same row; all VMEM in the loop is unconditional so that hipcc counts vmcnt exactly)
+#define VDB_LC()                                                                                       \
+    {                                                                                                  \
+        const uint32_t rr_ = r0 + oc_row;                                                              \
+        r_inrange = r_inrange_next;                                                                    \
         r_bit = rr_ & 31;                                                                              \
         r_mask = p.rowmask[rr_ >> 5]; /* raw loads only: they are consumed one stage later (VDB_SC) */ \
         r_alpha = p.alpha[rr_];                                                                        \
@@ -178,20 +193,19 @@ __global__ __launch_bounds__(NW * 64, 2) void fused_score_filter_kernel(FusedPar
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
     // ---- prologue: stage 0 -> LDS image 0, stage 1 -> registers (in flight)
-    VDB_LA(0, ra0, 0u, 0u) VDB_LA(1, ra1, 0u, 0u) VDB_LA(2, ra2, 0u, 0u) VDB_LA(3, ra3, 0u, 0u)
+    VDB_TILE_OFFSETS(0u)
+    VDB_LA(0, ra0, oa0, 0u) VDB_LA(1, ra1, oa1, 0u) VDB_LA(2, ra2, oa2, 0u) VDB_LA(3, ra3, oa3, 0u)
     VDB_LB(0, rb0, 0u) VDB_LB(1, rb1, 0u) VDB_LB(2, rb2, 0u) VDB_LB(3, rb3, 0u)
-    VDB_LC(0u)
+    VDB_LC()
     VDB_SA(0, ra0, 0u) VDB_SA(1, ra1, 0u) VDB_SA(2, ra2, 0u) VDB_SA(3, ra3, 0u)
     VDB_SB(0, rb0, 0u) VDB_SB(1, rb1, 0u) VDB_SB(2, rb2, 0u) VDB_SB(3, rb3, 0u)
     VDB_SC(0u, 0u)
     uint32_t tile = 0, ks = 0;             // stage being computed
     uint32_t tile1 = 0, ks1 = 1;           // stage st+1 (in the staging registers)
-    if (ks1 == KS) { ks1 = 0; tile1 = 1; }
-    if (total > 1) {
-        VDB_LA(0, ra0, tile1, ks1) VDB_LA(1, ra1, tile1, ks1) VDB_LA(2, ra2, tile1, ks1) VDB_LA(3, ra3, tile1, ks1)
-        VDB_LB(0, rb0, ks1) VDB_LB(1, rb1, ks1) VDB_LB(2, rb2, ks1) VDB_LB(3, rb3, ks1)
-        VDB_LC(tile1)
-    }
+    if (ks1 == KS) { ks1 = 0; tile1 = 1; VDB_TILE_OFFSETS(1u) }
+    VDB_LA(0, ra0, oa0, ks1) VDB_LA(1, ra1, oa1, ks1) VDB_LA(2, ra2, oa2, ks1) VDB_LA(3, ra3, oa3, ks1)
+    VDB_LB(0, rb0, ks1) VDB_LB(1, rb1, ks1) VDB_LB(2, rb2, ks1) VDB_LB(3, rb3, ks1)
+    VDB_LC()
     __syncthreads();
 
     // One K stage.  PARTIAL selects the code for a tile with fewer than TR valid rows (only the last
@@ -203,21 +217,27 @@ __global__ __launch_bounds__(NW * 64, 2) void fused_score_filter_kernel(FusedPar
         const uint32_t mt_valid = PARTIAL ? ((r1 - tr0 + 31) >> 5) : (uint32_t)(TR / 32);
         (void)st;
         uint32_t tile2 = tile1, ks2 = ks1 + 1;
-        if (ks2 == KS) { ks2 = 0; ++tile2; }
+        if (ks2 == KS) { ks2 = 0; ++tile2; VDB_TILE_OFFSETS(tile2) }   // wave-uniform, once per tile, VALU only
         const uint32_t nbuf = (st + 1) & 1;
         // staging step I: write one register of stage st+1 to the other LDS image, then refill it
         // (past the end of the range the stores go to an LDS image nobody reads and the loads are
         //  clamped to valid rows: keeping them unconditional is what lets the waits be counted)
-#define VDB_STEP_A(I, REG) { VDB_SA(I, REG, nbuf) VDB_LA(I, REG, tile2, ks2) }
+#ifdef VDB_DIAG   /* diagnostic build: ablate bit 32 skips the staging stores, bit 64 the staging loads */
+#define VDB_STEP_A(I, REG, OA) { if (!(p.ablate & 32u)) { VDB_SA(I, REG, nbuf) } if (!(p.ablate & 64u)) { VDB_LA(I, REG, OA, ks2) } }
+#define VDB_STEP_B(I, REG) { if (!(p.ablate & 32u)) { VDB_SB(I, REG, nbuf) } if (!(p.ablate & 64u)) { VDB_LB(I, REG, ks2) } }
+#define VDB_STEP_C() { if (!(p.ablate & 32u)) { VDB_SC(tile1, ks1) } if (!(p.ablate & 64u)) { VDB_LC() } }
+#else
+#define VDB_STEP_A(I, REG, OA) { VDB_SA(I, REG, nbuf) VDB_LA(I, REG, OA, ks2) }
 #define VDB_STEP_B(I, REG) { VDB_SB(I, REG, nbuf) VDB_LB(I, REG, ks2) }
-#define VDB_STEP_C() { VDB_SC(tile1, ks1) VDB_LC(tile2) }
+#define VDB_STEP_C() { VDB_SC(tile1, ks1) VDB_LC() }
+#endif
 
         const char* sa = smem + (st & 1) * C::STAGE_BYTES;
         const char* bptr = sa + C::A_BYTES + (qt * 32 + c) * ROWB + h * 16;
         const char* aptr = sa + (rp * MT * 32 + c) * ROWB + h * 16;
         if (p.ablate & 1u) {
             VDB_STEP_C()
-            VDB_STEP_A(0, ra0) VDB_STEP_A(1, ra1) VDB_STEP_A(2, ra2) VDB_STEP_A(3, ra3)
+            VDB_STEP_A(0, ra0, oa0) VDB_STEP_A(1, ra1, oa1) VDB_STEP_A(2, ra2, oa2) VDB_STEP_A(3, ra3, oa3)
             VDB_STEP_B(0, rb0) VDB_STEP_B(1, rb1) VDB_STEP_B(2, rb2) VDB_STEP_B(3, rb3)
         } else if constexpr (!PARTIAL) {
             // fragments double-buffered across the 4 K groups: group g+1 is read while g's MFMAs run
@@ -244,14 +264,14 @@ __global__ __launch_bounds__(NW * 64, 2) void fused_score_filter_kernel(FusedPar
     }
             // the row-constant step goes FIRST: its loads are loop-carried scalars that hipcc copies at the
             // loop latch, so they need the rest of the stage to land before that copy's wait
-            VDB_GROUP(0, fbA, faA, fbB, faB, VDB_STEP_C() VDB_STEP_A(0, ra0), VDB_STEP_A(1, ra1))
-            VDB_GROUP(1, fbB, faB, fbA, faA, VDB_STEP_A(2, ra2), VDB_STEP_A(3, ra3))
+            VDB_GROUP(0, fbA, faA, fbB, faB, VDB_STEP_C() VDB_STEP_A(0, ra0, oa0), VDB_STEP_A(1, ra1, oa1))
+            VDB_GROUP(1, fbB, faB, fbA, faA, VDB_STEP_A(2, ra2, oa2), VDB_STEP_A(3, ra3, oa3))
             VDB_GROUP(2, fbA, faA, fbB, faB, VDB_STEP_B(0, rb0), VDB_STEP_B(1, rb1))
             VDB_GROUP(3, fbB, faB, fbA, faA, VDB_STEP_B(2, rb2), VDB_STEP_B(3, rb3))
 #undef VDB_GROUP
         } else {
             VDB_STEP_C()
-            VDB_STEP_A(0, ra0) VDB_STEP_A(1, ra1) VDB_STEP_A(2, ra2) VDB_STEP_A(3, ra3)
+            VDB_STEP_A(0, ra0, oa0) VDB_STEP_A(1, ra1, oa1) VDB_STEP_A(2, ra2, oa2) VDB_STEP_A(3, ra3, oa3)
             VDB_STEP_B(0, rb0) VDB_STEP_B(1, rb1) VDB_STEP_B(2, rb2) VDB_STEP_B(3, rb3)
             // only the valid 32-row blocks (wave-uniform predicate)
 #pragma unroll
@@ -323,6 +343,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fused_score_filter_kernel(FusedPar
     for (; st < total; ++st) run_stage(st, std::true_type{});
     p.pool_cnt[sub] = pcnt;                                             // may exceed capl: the select flags it
 #undef VDB_LA
+#undef VDB_TILE_OFFSETS
 #undef VDB_LB
 #undef VDB_LC
 #undef VDB_SA
@@ -337,12 +358,13 @@ void launch_fused(const FusedParams& p, int nqt, uint32_t n_super, hipStream_t s
     switch (nqt) {
     case 1: hipLaunchKernelGGL((fused_score_filter_kernel<1, 1, 4>), grid, dim3(256), lds, s, p); break;
     case 2: hipLaunchKernelGGL((fused_score_filter_kernel<2, 2, 4>), grid, dim3(256), lds, s, p); break;
+    case 8: hipLaunchKernelGGL((fused_score_filter_kernel<8, 4, 8>), grid, dim3(512), lds, s, p); break;
     default: hipLaunchKernelGGL((fused_score_filter_kernel<4, 4, 4>), grid, dim3(256), lds, s, p); break;
     }
 }
 // sub-pools per query for a launch with n_wg row ranges: [n_wg][RP][2]
 uint32_t fused_subpools_per_query(int nqt, uint32_t n_wg) {
-    int rp = nqt == 1 ? CfgQ32::RP : nqt == 2 ? CfgQ64::RP : CfgQ128::RP;
+    int rp = nqt == 1 ? CfgQ32::RP : nqt == 2 ? CfgQ64::RP : nqt == 8 ? CfgQ256::RP : CfgQ128::RP;
     return n_wg * rp * 2;
 }
 

@@ -503,7 +503,8 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
         const uint32_t nb = std::min(SUPER, nq32 - q0);
         const uint32_t tiles = (nb + 31) / 32;
         // fused-kernel shape: 32 / 64 / 128 queries per workgroup; 2 workgroups per CU in flight
-        const int nqt = tiles > 2 ? 4 : (int)tiles;
+        static const bool shape8 = getenv("VDB_FUSED_SHAPE4") == nullptr;   // default: ONE 8-wave workgroup per CU, 256 queries share each fetched row tile (VDB_FUSED_SHAPE4 = two 4-wave workgroups of 128 queries)
+        const int nqt = (shape8 && tiles > 4) ? 8 : tiles > 2 ? 4 : (int)tiles;
         const uint32_t n_super = (tiles + nqt - 1) / nqt;          // workgroups along the query axis (1 or 2)
         const float* qp0 = ix->w_qp.p + (size_t)q0 * ld;
 
@@ -521,7 +522,7 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
             // thresholds: the sample's kp-th score (padding queries were given -inf by query_prep)
             sp.out_keys = ix->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->w_thr.p + q0; sp.ovf = nullptr;
             vdb::launch_select(sp, nb, s);
-            const uint32_t n_wg = std::min<uint32_t>(2u * (uint32_t)ix->n_cu / n_super, (n + 31) / 32);
+            const uint32_t n_wg = std::min<uint32_t>((nqt == 8 ? 1u : 2u) * (uint32_t)ix->n_cu / n_super, (n + 31) / 32);
             const uint32_t n_sub = vdb::fused_subpools_per_query(nqt, n_wg);
             vdb::FusedParams fp{ix->d_rows, ld, n, ix->w_qp.p, q0, ix->d_alpha, ix->d_beta, d_rowmask ? d_rowmask : ix->d_live,
                                 ix->w_thr.p, ix->w_pool.p - (size_t)q0 * n_sub * capl,
