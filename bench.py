@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--metric", type=int, default=METRIC)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--filter-mod", type=int, default=0, help="config-4 style pre-filter: only ids with id %% m == 0 are eligible")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,7 +108,16 @@ def main():
         del block, part
     index.flush()
     queries = gen_queries(B, dim, device)
-    searcher = ShardedSearcher(gpu_local_search(index), rank=rank, world=world)
+    mask_t, mask_bits = None, 0
+    if args.filter_mod > 1:
+        keep = (torch.arange(n_rows, device=device) % args.filter_mod == 0)
+        words = torch.zeros(((n_rows + 63) // 64) * 64, dtype=torch.bool, device=device)
+        words[:n_rows] = keep
+        weights = (2 ** torch.arange(8, device=device, dtype=torch.int32)).to(torch.uint8)
+        mask_t = (words.view(-1, 8).to(torch.uint8) * weights).sum(1).to(torch.uint8).contiguous()   # little-endian bit order
+        mask_bits = n_rows
+    searcher = ShardedSearcher(gpu_local_search(index, mask_ptr=mask_t.data_ptr() if mask_t is not None else 0,
+                                                mask_bits=mask_bits), rank=rank, world=world)
 
     def step():
         return searcher.search_batch(queries, k)
@@ -170,11 +180,12 @@ def main():
             c0, c1 = c * chunk, min((c + 1) * chunk, n_rows)
             rows_host[c0:c1] = gen_chunk(c, c1 - c0, dim, device).cpu().numpy()
         q_host = queries.cpu().numpy()
+        live_host = (np.arange(n_rows) % args.filter_mod == 0).astype(np.uint8) if args.filter_mod > 1 else None
         oracle.lib()
         done, t_cpu, recs, exact = 0, 0.0, [], True
         while done < B and (done < 2 or t_cpu < args.cpu_seconds):
             t1 = time.perf_counter()
-            oi, od = oracle.flat_search(args.metric, rows_host, q_host[done], k)
+            oi, od = oracle.flat_search(args.metric, rows_host, q_host[done], k, live=live_host)
             t_cpu += time.perf_counter() - t1
             recs.append(oracle.recall(oi, ids_g[done, :k]))
             exact &= bool(np.array_equal(oi, ids_g[done, :len(oi)]) and np.array_equal(od, dist_g[done, :len(od)]))
@@ -196,7 +207,8 @@ def main():
                        "n_rows": n_rows, "dim": dim, "batch": B, "k": k,
                        "distance": ["euclidean", "cosine", "dot"][args.metric],
                        "sharding": f"rows/{world}" if world > 1 else "single GPU",
-                       "inputs": "queries and outputs resident in HBM"},
+                       "inputs": "queries and outputs resident in HBM",
+                       "filter": f"id % {args.filter_mod} == 0 (device bitmask)" if args.filter_mod > 1 else None},
             "recall_at_10": recall,
             "path_stats": stats,
             "roofline": roofline,

@@ -112,7 +112,7 @@ class ShardedSearcher:
         return merge(g_ids, g_d, g_cnt, k)
 
 
-def gpu_local_search(index):
+def gpu_local_search(index, mask_ptr=0, mask_bits=0):
     """local_search callable over a GpuFlatIndex with everything resident in HBM."""
     def run(queries, k):
         B, d = queries.shape
@@ -121,6 +121,7 @@ def gpu_local_search(index):
         dists = torch.empty((B, k), dtype=torch.float32, device=dev)
         counts = torch.empty((B,), dtype=torch.int32, device=dev)
         index.search_batch_device(queries.data_ptr(), B, d, k, ids.data_ptr(), dists.data_ptr(), counts.data_ptr(),
-                                  stream=torch.cuda.current_stream(dev).cuda_stream)
+                                  stream=torch.cuda.current_stream(dev).cuda_stream, mask_ptr=mask_ptr,
+                                  mask_bits=mask_bits)
         return ids, dists, counts
     return run
