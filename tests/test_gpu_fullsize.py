@@ -92,3 +92,19 @@ def test_full_size_prefilter_and_k30(big):
         # reference post-filter result (prefix property)
         post = [i for i in fi[b] if i % 4 == 0][:K]
         assert list(gi[b][:len(post)]) == post
+
+
+def test_full_size_k100_stays_on_the_mfma_path(big):
+    """Config-3 style k = 100 (kp = 128): the sample must be sized so that no pool overflows and every
+    query is certified (a too-small sample once sent 1019 of 1024 queries to the exact fallback)."""
+    vdb, rows, queries = big["vdb"], big["rows"], big["queries"]
+    ix = build(vdb, 2, rows)
+    q_h = queries[:64].cpu().numpy()
+    gi, gd, gc = ix.search_batch_arrays(q_h, 100)
+    st = ix.last_stats()
+    assert st["kprime"] == 128 and st["exact_queries"] == 0 and st["pool_overflows"] == 0, st
+    assert np.all(gc == 100)
+    rows_h = rows.cpu().numpy()
+    for b in (3, 40):
+        oi, od = oracle.flat_search(2, rows_h, q_h[b], 100)
+        assert np.array_equal(gi[b], oi) and np.array_equal(gd[b], od)

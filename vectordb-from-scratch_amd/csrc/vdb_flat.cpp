@@ -481,8 +481,16 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
 
     // ---- sizes of the threshold sample and the candidate pools
     const bool small = n <= SMALL_N;
-    uint32_t S = small ? n : std::min<uint32_t>(16384u, std::max<uint32_t>(2048u, pow2_ceil(n / 256u)));
-    if (const char* e = getenv("VDB_SAMPLE")) { if (!small) S = std::min<uint32_t>(n, std::max(64, atoi(e))); }
+    // Threshold sample size S: the fused pass keeps about n*kp/S keys per query, spread over 512 private
+    // sub-pools of 64 slots and gathered into 16384 LDS slots by the select.  S is chosen so that this
+    // expectation stays near 8000 or below (mean sub-pool fill <= 16), and the sample costs <= ~3 % of the
+    // fused pass for k = 10.
+    uint32_t S = n;
+    if (!small) {
+        uint64_t want = std::max<uint64_t>(n / 256u, (uint64_t)n * kp / 8000u);
+        S = (uint32_t)std::min<uint64_t>(65536u, std::max<uint64_t>(2048u, pow2_ceil(want)));
+        if (const char* e = getenv("VDB_SAMPLE")) S = std::min<uint32_t>(n, std::max(64, atoi(e)));
+    }
     // candidate pools: one private sub-pool per (query, row range, row part, lane half) of the fused kernel
     const uint32_t capl = 64;
     // sub-pools in one pass = queries * row ranges * row parts * 2 = 512 * n_cu for every kernel shape
