@@ -74,6 +74,12 @@ int vdb_flat_add_bulk(vdb_flat_index *h, const uint64_t *ids, uint64_t first_id,
 int vdb_flat_add_bulk_device(vdb_flat_index *h, const uint64_t *ids, uint64_t first_id,
                              const float *d_rows, size_t n, size_t dim);
 
+/* Bulk-load the reference's mmap vector file (src/persistence/mmap.rs:13-15 header `[dim u32 LE][count u32 LE]`,
+ * :77-84 body = row-major little-endian f32): the file is memory-mapped and handed to the device in
+ * large chunks instead of `count` add() calls.  The file has no id column: row i gets id first_id + i.
+ * *out_count receives the number of rows loaded. */
+int vdb_flat_load_vector_file(vdb_flat_index *h, const char *path, uint64_t first_id, size_t *out_count);
+
 /* Index::remove(id)  src/index.rs:16, src/flat_index.rs:43-46.  Absent id is VDB_OK. */
 int vdb_flat_remove(vdb_flat_index *h, uint64_t id);
 

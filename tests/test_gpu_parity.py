@@ -285,3 +285,25 @@ def test_recall_is_one(vdb):
     gi, _, gc = ix.search_batch_arrays(q, 10)
     rec = [oracle.recall(oracle.flat_search(1, rows, q[b], 10)[0], gi[b, :gc[b]]) for b in range(0, 32, 4)]
     assert min(rec) == 1.0
+
+
+def test_mmap_vector_file_bulk_load(vdb, tmp_path):
+    """The reference's mmap vector file (src/persistence/mmap.rs:13-15,77-84): 8-byte header
+    [dim u32 LE][count u32 LE] + row-major LE f32 rows, loaded in one call."""
+    rng = np.random.default_rng(21)
+    n, d = 20001, 37
+    rows = rng.random((n, d), dtype=np.float32)
+    path = tmp_path / "vectors.bin"
+    with open(path, "wb") as f:
+        f.write(np.array([d, n], dtype="<u4").tobytes())
+        f.write(rows.astype("<f4").tobytes())
+    ix = vdb.GpuFlatIndex(vdb.DistanceMetric.Euclidean, keep_host_copy=False)
+    assert ix.load_vector_file(str(path), first_id=100) == n and ix.len() == n and ix.dim() == d
+    q = rng.random((5, d), dtype=np.float32)
+    check_against_oracle(vdb, 0, rows, q, 10, ids=np.arange(100, 100 + n, dtype=np.uint64), ix=ix)
+    with open(path, "r+b") as f:                     # truncated body -> error, nothing loaded
+        f.truncate(8 + (n - 1) * d * 4)
+    ix2 = vdb.GpuFlatIndex(vdb.DistanceMetric.Euclidean)
+    with pytest.raises(vdb.VectorDbError):
+        ix2.load_vector_file(str(path))
+    assert ix2.len() == 0

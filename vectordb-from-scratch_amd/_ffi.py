@@ -11,7 +11,7 @@ OK, ERR_DIMENSION_MISMATCH, ERR_INVALID_VECTOR, ERR_NAN, ERR_DEVICE, ERR_INVALID
 # every symbol include/vdb_flat.h declares
 SYMBOLS = [
     "vdb_flat_create", "vdb_flat_destroy", "vdb_flat_add", "vdb_flat_add_bulk", "vdb_flat_add_bulk_device",
-    "vdb_flat_remove", "vdb_flat_get_vector", "vdb_flat_len", "vdb_flat_metric", "vdb_flat_dim",
+    "vdb_flat_load_vector_file", "vdb_flat_remove", "vdb_flat_get_vector", "vdb_flat_len", "vdb_flat_metric", "vdb_flat_dim",
     "vdb_flat_reserve", "vdb_flat_flush", "vdb_flat_search", "vdb_flat_search_batch",
     "vdb_flat_search_batch_device", "vdb_merge_topk_device", "vdb_flat_set_profile", "vdb_flat_last_stats", "vdb_last_error",
     "vdb_abi_version", "vdb_build_arch",
@@ -38,6 +38,7 @@ def lib():
     L.vdb_flat_add.argtypes = [vp, u64, fp, sz]
     L.vdb_flat_add_bulk.argtypes = [vp, u64p, u64, fp, sz, sz]
     L.vdb_flat_add_bulk_device.argtypes = [vp, u64p, u64, vp, sz, sz]
+    L.vdb_flat_load_vector_file.argtypes = [vp, c.c_char_p, u64, szp]
     L.vdb_flat_remove.argtypes = [vp, u64]
     L.vdb_flat_get_vector.argtypes = [vp, u64, fp, sz, szp]
     L.vdb_flat_len.argtypes = [vp]

@@ -11,6 +11,11 @@
 //   live     [cap/32]  u32   tombstone bitmask (remove() clears a bit; rows are append-only)
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -740,6 +745,35 @@ int vdb_flat_add_bulk_device(vdb_flat_index* ix, const uint64_t* ids, uint64_t f
     ix->zero_valid = false;
     ix->rank_valid = false;
     return VDB_OK;
+}
+
+int vdb_flat_load_vector_file(vdb_flat_index* ix, const char* path, uint64_t first_id, size_t* out_count) {
+    if (!ix || !path) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    if (out_count) *out_count = 0;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(VDB_ERR_INVALID_ARGUMENT, "cannot open %s", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 8) {
+        close(fd);
+        return fail(VDB_ERR_INVALID_ARGUMENT, "File too small for header");          // mmap.rs:52-54
+    }
+    void* map = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return fail(VDB_ERR_INVALID_ARGUMENT, "mmap of %s failed", path);
+    const unsigned char* b = (const unsigned char*)map;
+    auto le32 = [&](size_t o) { return (uint32_t)b[o] | ((uint32_t)b[o + 1] << 8) | ((uint32_t)b[o + 2] << 16) | ((uint32_t)b[o + 3] << 24); };
+    const size_t dim = le32(0), count = le32(4);                                      // mmap.rs:161-172
+    int rc = VDB_OK;
+    if (dim == 0 && count) rc = fail(VDB_ERR_INVALID_ARGUMENT, "vector file with dimension 0");
+    else if ((size_t)st.st_size < 8 + count * dim * 4) rc = fail(VDB_ERR_INVALID_ARGUMENT, "vector file truncated: %zu rows of %zu floats need %zu bytes", count, dim, 8 + count * dim * 4);
+    else if (count) {
+        // the body starts at byte 8, so rows are 4-byte aligned; x86 is little-endian like the file
+        rc = vdb_flat_add_bulk(ix, nullptr, first_id, (const float*)(b + 8), count, dim);
+        if (rc == VDB_OK) rc = vdb_flat_flush(ix);
+    }
+    munmap(map, (size_t)st.st_size);
+    if (rc == VDB_OK && out_count) *out_count = count;
+    return rc;
 }
 
 int vdb_flat_remove(vdb_flat_index* ix, uint64_t id) {

@@ -6,6 +6,7 @@ borrow, so the host keeps one anyway) and calls the hand-written HIP kernels thr
 ABI of include/vdb_flat.h.  There is no CPU search path."""
 import abc
 import ctypes
+import os
 
 import numpy as np
 
@@ -190,6 +191,14 @@ class GpuFlatIndex(Index):
         rc = self._L.vdb_flat_add_bulk_device(self._h, idp, int(first_id), ctypes.c_void_p(dev_ptr), int(n), int(dim))
         if rc:
             _raise(rc)
+
+    def load_vector_file(self, path, first_id=0):
+        """Bulk-load the reference's mmap vector file (src/persistence/mmap.rs); returns the row count."""
+        n = ctypes.c_size_t()
+        rc = self._L.vdb_flat_load_vector_file(self._h, os.fsencode(path), int(first_id), ctypes.byref(n))
+        if rc:
+            _raise(rc)
+        return n.value
 
     def reserve(self, rows, dim):
         rc = self._L.vdb_flat_reserve(self._h, int(rows), int(dim))
