@@ -117,7 +117,7 @@ def main():
         mask_t = (words.view(-1, 8).to(torch.uint8) * weights).sum(1).to(torch.uint8).contiguous()   # little-endian bit order
         mask_bits = n_rows
     searcher = ShardedSearcher(gpu_local_search(index, mask_ptr=mask_t.data_ptr() if mask_t is not None else 0,
-                                                mask_bits=mask_bits), rank=rank, world=world)
+                                                mask_bits=mask_bits, reuse_outputs=True), rank=rank, world=world)
 
     def step():
         return searcher.search_batch(queries, k)
