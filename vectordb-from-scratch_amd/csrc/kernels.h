@@ -121,6 +121,8 @@ void launch_fused(const FusedParams& p, int nqt, uint32_t n_super, hipStream_t s
 size_t fused_lds_bytes(int nqt);
 uint32_t fused_tile_rows(int nqt);
 uint32_t fused_subpools_per_query(int nqt, uint32_t n_wg);
+// LDS-DMA variant of the headline shape (nqt = 8): same results, stages brought in by global_load_lds
+void launch_fused_dma(const FusedParams& p, uint32_t n_super, hipStream_t s);
 
 // ---------------------------------------------------------------- exact re-rank + certification
 struct RerankParams {

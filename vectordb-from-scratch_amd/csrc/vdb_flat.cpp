@@ -542,7 +542,9 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
                                 ix->w_subcnt.p - (size_t)q0 * n_sub, capl, n_wg,
                                 getenv("VDB_FUSED_ABLATE") ? (uint32_t)atoi(getenv("VDB_FUSED_ABLATE")) : 0u};
             if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
-            vdb::launch_fused(fp, nqt, n_super, s);
+            static const bool use_dma = getenv("VDB_FUSED_REGSTAGE") == nullptr;   // default: LDS-DMA staging (VDB_FUSED_REGSTAGE=1: register-staged variant, same results)
+            if (use_dma && nqt == 8) vdb::launch_fused_dma(fp, n_super, s);
+            else vdb::launch_fused(fp, nqt, n_super, s);
             if (ix->profile) {
                 // one super-tile per event pair: wait here so the pair can be reused (profiling mode only)
                 HIP_TRY(hipEventRecord(ix->ev1, s));
