@@ -307,3 +307,25 @@ def test_mmap_vector_file_bulk_load(vdb, tmp_path):
     with pytest.raises(vdb.VectorDbError):
         ix2.load_vector_file(str(path))
     assert ix2.len() == 0
+
+
+def test_concurrent_searches_from_several_threads(vdb):
+    """search may be called concurrently on one handle (the server holds RwLock::read() around it,
+    src/server/routes.rs:244,:342); ctypes releases the GIL, the library serialises device submission."""
+    import threading
+    rng = np.random.default_rng(23)
+    rows = rng.random((30000, 24), dtype=np.float32)
+    ix = make_index(vdb, 0, rows)
+    qs = [rng.random((11, 24), dtype=np.float32) for _ in range(6)]
+    want = [ix.search_batch_arrays(q, 5) for q in qs]
+    got = [None] * 6
+
+    def work(i):
+        for _ in range(5):
+            got[i] = ix.search_batch_arrays(qs[i], 5)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(6)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for w, g in zip(want, got):
+        assert all(np.array_equal(a, b) for a, b in zip(w, g))
