@@ -155,12 +155,36 @@ struct ExactScanParams {
 };
 void launch_exact_scan(const ExactScanParams& p, hipStream_t s);
 
+// Bounded exact scan for up to 8 uncertified queries in ONE pass over the rows: a row is kept for query j
+// only if its exact distance is <= bound_j, the k-th exact distance the re-rank already produced (an upper
+// bound of the true k-th distance), so the survivors are a handful of keys per query.
+struct ExactMultiParams {
+    const float* rows; uint32_t ld; uint32_t dim; uint32_t n_rows;
+    const float* qp; const float* qnorm;               // padded query block and norms of the whole batch
+    const float* nd; const uint32_t* rowmask; const uint32_t* idrank;
+    int metric;
+    uint32_t nqf; uint32_t qidx[8];                    // batch indices of the queries of this pass
+    const float* prev_dists; const uint32_t* prev_counts; uint32_t k;   // re-rank outputs: bound = dists[q*k + k-1] if counts[q] == k
+    uint64_t* keys; uint32_t cap; uint32_t* cnt;       // keys[j*cap + slot], cnt[j] (may exceed cap: overflow)
+    uint32_t* status;
+};
+void launch_exact_multi(const ExactMultiParams& p, hipStream_t s);
+
 struct EmitParams {                                    // sorted exact keys -> (id, dist) outputs
     const uint64_t* keys; uint32_t cnt_max; const uint32_t* cnt;
     const uint32_t* rank2row; const uint64_t* row_ids;
     uint64_t* out_ids; float* out_dists; uint32_t* out_count; uint32_t k;
     uint32_t accumulate;                               // 1: *out_count += n (chunked large k), 0: *out_count = n
 };
+// emit for several queries at once: query j (= blockIdx.y) reads keys + j*key_stride, cnt[j] and writes
+// to out_*[qidx[j]*k ..] / out_count[qidx[j]]
+struct EmitMultiParams {
+    const uint64_t* keys; uint32_t key_stride; const uint32_t* cnt;
+    const uint32_t* rank2row; const uint64_t* row_ids;
+    uint64_t* out_ids; float* out_dists; uint32_t* out_count; uint32_t k;
+    uint32_t nqf; uint32_t qidx[8];
+};
+void launch_emit_multi(const EmitMultiParams& p, hipStream_t s);
 void launch_emit(const EmitParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------- multi-GPU partial merge

@@ -618,6 +618,111 @@ void launch_exact_scan(const ExactScanParams& p, hipStream_t s) {
     hipLaunchKernelGGL(exact_scan_kernel, dim3((p.n_rows + 255) / 256), dim3(256), 0, s, p);
 }
 
+// One pass over the rows for up to 8 queries: one thread per row, the row is read once (16 floats at a
+// time) and folded against every query in the reference's order (independent chains -> ILP).
+__global__ __launch_bounds__(256) void exact_multi_kernel(ExactMultiParams p) {
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= p.n_rows) return;
+    if (p.rowmask && !((p.rowmask[row >> 5] >> (row & 31)) & 1u)) return;
+    const float* x = p.rows + (size_t)row * p.ld;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.0f;
+    const uint32_t d = p.dim;
+    uint32_t i = 0;
+    for (; i + 16 <= d; i += 16) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + i + 4 * u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < (int)p.nqf) {                                           // wave-uniform
+                const float* q = p.qp + (size_t)p.qidx[j] * p.ld + i;       // uniform address: scalar loads
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 a = *reinterpret_cast<const float4*>(q + 4 * u);
+                    if (p.metric == EUCLID) {
+                        float t;
+                        t = __fsub_rn(a.x, v[u].x); s[j] = __fadd_rn(s[j], __fmul_rn(t, t));
+                        t = __fsub_rn(a.y, v[u].y); s[j] = __fadd_rn(s[j], __fmul_rn(t, t));
+                        t = __fsub_rn(a.z, v[u].z); s[j] = __fadd_rn(s[j], __fmul_rn(t, t));
+                        t = __fsub_rn(a.w, v[u].w); s[j] = __fadd_rn(s[j], __fmul_rn(t, t));
+                    } else {
+                        s[j] = __fadd_rn(s[j], __fmul_rn(a.x, v[u].x));
+                        s[j] = __fadd_rn(s[j], __fmul_rn(a.y, v[u].y));
+                        s[j] = __fadd_rn(s[j], __fmul_rn(a.z, v[u].z));
+                        s[j] = __fadd_rn(s[j], __fmul_rn(a.w, v[u].w));
+                    }
+                }
+            }
+        }
+    }
+    for (; i < d; ++i) {
+        const float xv = x[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < (int)p.nqf) {
+                const float a = p.qp[(size_t)p.qidx[j] * p.ld + i];
+                if (p.metric == EUCLID) { float t = __fsub_rn(a, xv); s[j] = __fadd_rn(s[j], __fmul_rn(t, t)); }
+                else s[j] = __fadd_rn(s[j], __fmul_rn(a, xv));
+            }
+        }
+    }
+    const float xn = p.nd[row];
+    const uint32_t rk = p.idrank ? p.idrank[row] : row;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < (int)p.nqf) {
+            const uint32_t qi = p.qidx[j];
+            float dist;
+            if (p.metric == EUCLID) dist = __builtin_sqrtf(s[j]);
+            else if (p.metric == DOT) dist = -s[j];
+            else {
+                float sim = __fdiv_rn(s[j], __fmul_rn(p.qnorm[qi], xn));
+                if (sim < -1.0f) sim = -1.0f;
+                if (sim > 1.0f) sim = 1.0f;
+                dist = __fsub_rn(1.0f, sim);
+            }
+            if (dist != dist) atomicOr(p.status, ST_NAN);
+            const float bound = (p.prev_counts[qi] == p.k) ? p.prev_dists[(size_t)qi * p.k + p.k - 1]
+                                                           : __uint_as_float(0x7f800000u);
+            if (!(dist > bound)) {                                          // ties with the bound are kept
+                const uint32_t slot = atomicAdd(&p.cnt[j], 1u);
+                if (slot < p.cap) p.keys[(size_t)j * p.cap + slot] = ((uint64_t)f32_to_ordered(dist) << 32) | rk;
+            }
+        }
+    }
+}
+void launch_exact_multi(const ExactMultiParams& p, hipStream_t s) {
+    if (!p.n_rows || !p.nqf) return;
+    hipLaunchKernelGGL(exact_multi_kernel, dim3((p.n_rows + 255) / 256), dim3(256), 0, s, p);
+}
+
+__global__ __launch_bounds__(256) void emit_multi_kernel(EmitMultiParams p) {
+    const uint32_t j = blockIdx.y;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t qi = p.qidx[j];
+    uint32_t cnt = p.cnt[j];
+    if (cnt > p.k) cnt = p.k;
+    if (i == 0) p.out_count[qi] = cnt;
+    if (i >= p.k) return;
+    const size_t o = (size_t)qi * p.k + i;
+    if (i < cnt) {
+        uint64_t key = p.keys[(size_t)j * p.key_stride + i];
+        uint32_t rk = (uint32_t)key;
+        uint32_t row = p.rank2row ? p.rank2row[rk] : rk;
+        p.out_ids[o] = p.row_ids[row];
+        p.out_dists[o] = ordered_to_f32((uint32_t)(key >> 32));
+    } else {
+        p.out_ids[o] = ~0ull;
+        p.out_dists[o] = __uint_as_float(0x7fc00000u);
+    }
+}
+void launch_emit_multi(const EmitMultiParams& p, hipStream_t s) {
+    if (!p.k || !p.nqf) return;
+    hipLaunchKernelGGL(emit_multi_kernel, dim3((p.k + 255) / 256, p.nqf), dim3(256), 0, s, p);
+}
+
 __global__ __launch_bounds__(256) void emit_kernel(EmitParams p) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cnt = *p.cnt;

@@ -576,18 +576,59 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
     const uint32_t status = ix->h_flags[0];
     if (status & vdb::ST_ZERO_QUERY)
         return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
-    // ---- exact fallback for the queries the MFMA path could not certify
+    // ---- exact fallback for the queries the MFMA path could not certify.  Up to 8 of them share one pass
+    // over the rows; a row survives for a query only if its exact distance is <= the k-th exact distance
+    // the re-rank already found (a valid upper bound), so each query is left with a handful of keys.
     uint32_t n_fallback = 0;
     const bool force_exact = getenv("VDB_FORCE_EXACT") != nullptr;
+    std::vector<uint32_t> todo;
     for (uint32_t q = 0; q < nq32; ++q) {
         bool cert = ix->h_flags[4 + q] != 0, ovf = ix->h_flags[4 + nq32 + q] != 0;
         if (ovf) ++ix->stats[2];
         if (!cert) ++ix->stats[6];
         if (cert && !ovf && !force_exact) continue;
-        if ((rc = exact_one(ix, s, q, k, d_rowmask, d_out_ids + (size_t)q * k, d_out_dists + (size_t)q * k,
-                            d_out_counts + q, 0.f)))
-            return rc;
-        ++n_fallback;
+        todo.push_back(q);
+    }
+    n_fallback = (uint32_t)todo.size();
+    if (!todo.empty()) {
+        const uint32_t cap = 32768;
+        if ((rc = ensure_ranks(ix))) return rc;
+        if ((rc = ix->w_exact.ensure(std::max<size_t>((size_t)8 * cap, n)))) return rc;
+        if ((rc = ix->w_exsel.ensure((size_t)8 * MAX_SELECT + 8))) return rc;
+        uint32_t* d_cnt8 = ix->w_cnt.p + 3 * SUPER;            // [8] survivors per query, [8..16) select counts
+        std::vector<uint32_t> dense;                             // queries whose bounded pass overflowed
+        for (size_t g0 = 0; g0 < todo.size(); g0 += 8) {
+            const uint32_t nqf = (uint32_t)std::min<size_t>(8, todo.size() - g0);
+            HIP_TRY(hipMemsetAsync(d_cnt8, 0, 16 * 4, s));
+            vdb::ExactMultiParams ep{};
+            ep.rows = ix->d_rows; ep.ld = ld; ep.dim = ix->dim; ep.n_rows = n; ep.qp = ix->w_qp.p; ep.qnorm = ix->w_qnorm.p;
+            ep.nd = ix->d_nd; ep.rowmask = d_rowmask; ep.idrank = ix->ids_monotone ? nullptr : ix->d_idrank.p;
+            ep.metric = ix->metric; ep.nqf = nqf;
+            for (uint32_t j = 0; j < nqf; ++j) ep.qidx[j] = todo[g0 + j];
+            ep.prev_dists = d_out_dists; ep.prev_counts = d_out_counts; ep.k = (uint32_t)k;
+            ep.keys = ix->w_exact.p; ep.cap = cap; ep.cnt = d_cnt8; ep.status = d_status;
+            vdb::launch_exact_multi(ep, s);
+            uint32_t h_cnt[8];
+            HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt8, nqf * 4, hipMemcpyDeviceToHost, s));
+            vdb::SelectParams sp{};
+            sp.keys = ix->w_exact.p; sp.stride = cap; sp.counts = d_cnt8; sp.n_fixed = 0; sp.cap = cap; sp.kk = (uint32_t)k;
+            sp.out_keys = ix->w_exsel.p; sp.out_stride = MAX_SELECT; sp.out_cnt = d_cnt8 + 8;
+            vdb::launch_select(sp, nqf, s);
+            vdb::EmitMultiParams em{};
+            em.keys = ix->w_exsel.p; em.key_stride = MAX_SELECT; em.cnt = d_cnt8 + 8;
+            em.rank2row = ix->ids_monotone ? nullptr : ix->d_rank2row.p; em.row_ids = ix->d_row_ids;
+            em.out_ids = d_out_ids; em.out_dists = d_out_dists; em.out_count = d_out_counts; em.k = (uint32_t)k; em.nqf = nqf;
+            for (uint32_t j = 0; j < nqf; ++j) em.qidx[j] = todo[g0 + j];
+            vdb::launch_emit_multi(em, s);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s));
+            for (uint32_t j = 0; j < nqf; ++j)
+                if (h_cnt[j] > cap) dense.push_back(todo[g0 + j]);   // e.g. every row ties with the bound
+        }
+        for (uint32_t q : dense)
+            if ((rc = exact_one(ix, s, q, k, d_rowmask, d_out_ids + (size_t)q * k, d_out_dists + (size_t)q * k,
+                                d_out_counts + q, 0.f)))
+                return rc;
     }
     ix->stats[0] = nq32 - n_fallback;
     ix->stats[1] = n_fallback;
