@@ -76,35 +76,45 @@ class ShardedSearcher:
         self.merge = merge
         self._pack = self._gath = None
 
+    def _buffers(self, B, k, device):
+        """One int32 buffer per rank holds ids (two words each), distances (bit pattern), counts and the
+        status word; the local search writes its outputs straight into it, so the exchange is ONE
+        all-gather with no packing copies."""
+        words = B * (3 * k + 1) + 1
+        if self._pack is None or self._pack.numel() != words + (words & 1) or self._pack.device != device:
+            self._pack = torch.zeros((words + (words & 1),), dtype=torch.int32, device=device)
+            self._gath = torch.empty((self.world * self._pack.numel(),), dtype=torch.int32, device=device)
+        pk = self._pack
+        ids = pk[:2 * B * k].view(torch.int64).view(B, k)
+        dists = pk[2 * B * k:3 * B * k].view(torch.float32).view(B, k)
+        counts = pk[3 * B * k:3 * B * k + B]
+        return pk, ids, dists, counts, words
+
     def search_batch(self, queries, k):
         code = 0
         err = None
+        B = queries.shape[0]
+        if self.world > 1:
+            pk, ids, dists, counts, words = self._buffers(B, k, queries.device)
+            outs = (ids, dists, counts)
+        else:
+            outs = None
         try:
-            ids, dists, counts = self.local_search(queries, k)
+            res = self.local_search(queries, k, outs) if outs is not None else self.local_search(queries, k)
+            if outs is not None and res[0].data_ptr() != ids.data_ptr():      # a local search that ignores `outs`
+                ids.copy_(res[0]); dists.copy_(res[1]); counts.copy_(res[2].to(torch.int32))
+            elif outs is None:
+                ids, dists, counts = res
         except VectorDbError as e:            # keep the collective call pattern identical on every rank
             err, code = e, _ERR_CODE.get(type(e), 4)
-            B = queries.shape[0]
-            ids = torch.zeros((B, k), dtype=torch.int64, device=queries.device)
-            dists = torch.zeros((B, k), dtype=torch.float32, device=queries.device)
-            counts = torch.zeros((B,), dtype=torch.int32, device=queries.device)
+            if outs is None:
+                raise
+            ids.zero_(); dists.zero_(); counts.zero_()
         if self.world == 1:
-            if err:
-                raise err
             return ids, dists, counts
-        B = ids.shape[0]
-        # ONE all-gather: ids (as two int32 words), distances (bit pattern), counts and the status word are
-        # packed into a single int32 buffer of B*(3k+1)+1 words per rank
-        words = B * (3 * k + 1) + 1
-        if self._pack is None or self._pack.numel() != words or self._pack.device != ids.device:
-            self._pack = torch.empty((words,), dtype=torch.int32, device=ids.device)
-            self._gath = torch.empty((self.world * words,), dtype=torch.int32, device=ids.device)
-        pk = self._pack
-        pk[:2 * B * k].copy_(ids.contiguous().view(torch.int32).view(-1))
-        pk[2 * B * k:3 * B * k].copy_(dists.contiguous().view(torch.int32).view(-1))
-        pk[3 * B * k:3 * B * k + B].copy_(counts.to(torch.int32))
         pk[words - 1] = code
         dist.all_gather_into_tensor(self._gath, pk, group=self.group)
-        g = self._gath.view(self.world, words)
+        g = self._gath.view(self.world, pk.numel())
         g_ids = g[:, :2 * B * k].contiguous().view(torch.int64).view(self.world, B, k)
         g_d = g[:, 2 * B * k:3 * B * k].contiguous().view(torch.float32).view(self.world, B, k)
         g_cnt = g[:, 3 * B * k:3 * B * k + B].contiguous()
@@ -124,11 +134,13 @@ def gpu_local_search(index, mask_ptr=0, mask_bits=0, reuse_outputs=False):
     returns the same three output tensors on every call (overwritten by the next search)."""
     cache = {}
 
-    def run(queries, k):
+    def run(queries, k, outs=None):
         B, d = queries.shape
         dev = queries.device
         key = (B, k, dev)
-        if reuse_outputs and key in cache:
+        if outs is not None:                    # caller-provided buffers (the packed exchange buffer)
+            ids, dists, counts = outs
+        elif reuse_outputs and key in cache:
             ids, dists, counts = cache[key]
         else:
             ids = torch.empty((B, k), dtype=torch.int64, device=dev)
