@@ -169,7 +169,7 @@ def main():
             traffic = None
     roofline = {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "kernel": "fused_score_filter_dma_kernel (8 waves, 128 rows x 256 queries)", "kernel_ms": round(kern_ms, 4),
+                "kernel": "fused_score_filter_dma3_kernel (8 waves, 128 rows x 256 queries, 3-image LDS-DMA ring)", "kernel_ms": round(kern_ms, 4),
                 "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
                 "hbm_frac_algorithmic": round(alg_bytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if kern_ms > 0 else None}
 

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Copy the newest rocprofv3 outputs under gpurun_out/ (tools/round_profile.sh) into profiles/ with a tag."""
+import collections, csv, glob, json, os, shutil, sys
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def newest(pat):
+    fs = glob.glob(os.path.join(root, pat)); fs.sort(key=os.path.getmtime); return fs[-1]
+shutil.copy(newest("gpurun_out/profS/*/*kernel_stats.csv"), os.path.join(root, f"profiles/{tag}_kernel_stats.csv"))
+out = {}
+for d in ("pmcA", "pmcB", "pmcF", "pmcW"):
+    cc = newest(f"gpurun_out/{d}/*/*counter_collection.csv"); kt = cc.replace("counter_collection", "kernel_trace")
+    trace = {r["Dispatch_Id"]: r for r in csv.DictReader(open(kt))}
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); name = None
+    for r in csv.DictReader(open(cc)):
+        if "fused" in r["Kernel_Name"]:
+            agg[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"]); name = r["Kernel_Name"]
+    last = sorted(agg, key=int)[-1]; c = dict(agg[last]); t = trace[last]
+    c["duration_ns"] = int(t["End_Timestamp"]) - int(t["Start_Timestamp"])
+    if "GRBM_GUI_ACTIVE" in c:
+        cyc = c["GRBM_GUI_ACTIVE"] / 8; c["cycles_per_xcd"] = cyc; c["eff_clock_ghz"] = cyc / c["duration_ns"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c: c["mfma_pipe_util"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc
+        if "SQ_LDS_IDX_ACTIVE" in c: c["lds_active_frac_per_cu"] = c["SQ_LDS_IDX_ACTIVE"] / 256 / cyc
+    out[d] = c
+fetch = out["pmcF"]["FETCH_SIZE"] * 1024; write = out["pmcW"]["WRITE_SIZE"] * 1024
+out["_notes"] = {"kernel": name, "workload": "bench.py default: 1Mx768 f32 cosine batch 256 k=10 (one launch)",
+    "fetch_raw_bytes": fetch, "write_bytes": write,
+    "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request for 16-B/lane streaming reads (MI355X_MICROARCH.md, HBM section); calibrated in round 1 on the 384 MB device-to-device copy of bench.py's index build (WRITE_SIZE 366.2 MiB exact, FETCH_SIZE 183.1 MiB = 1/2)",
+    "hbm_bytes_per_launch": 2 * fetch + write, "algorithmic_bytes": 3072786432}
+json.dump(out, open(os.path.join(root, f"profiles/{tag}_pmc_fused.json"), "w"), indent=1)
+json.dump({"hbm_bytes_per_launch": 2 * fetch + write, "fetch_size_raw_bytes": fetch, "write_size_bytes": write,
+           "source": f"profiles/{tag}_pmc_fused.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled per the gfx950 correction)",
+           "workload": "bench.py default (1Mx768 f32, batch 256, k=10, 1 GPU)"}, open(os.path.join(root, "profiles/traffic.json"), "w"), indent=1)
+bench = open(os.path.join(root, "gpurun_out/bench_final.json")).read().strip().splitlines()[-1]
+open(os.path.join(root, f"profiles/{tag}_bench_line.json"), "w").write(bench + "\n")
+print(json.dumps({k: v for k, v in out.items() if k != "_notes"}, indent=1)[:1800]); print(out["_notes"]["hbm_bytes_per_launch"])

@@ -42,6 +42,22 @@ __host__ __device__ inline uint64_t make_key(float score, uint32_t row) {
     return ((uint64_t)hi << 32) | row;
 }
 
+// Raw pool entry written by the fused kernels' epilogue: the score's f32 bits and the row (0xffffffff =
+// ineligible row).  The select's gather turns it into an ordered candidate key (cheaper than doing the
+// order-preserving transform and the NaN test inside the MFMA kernel, where every VALU instruction
+// takes cycles from the f32 MFMA pipe).
+__host__ __device__ inline uint64_t make_raw_key(float score, uint32_t row) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return ((uint64_t)__float_as_uint(score) << 32) | row;
+#else
+    union { float f; uint32_t u; } c; c.f = score; return ((uint64_t)c.u << 32) | row;
+#endif
+}
+__device__ inline uint64_t raw_to_key(uint64_t raw) {
+    const uint32_t row = (uint32_t)raw;
+    return row == 0xffffffffu ? EMPTY_KEY : make_key(__uint_as_float((uint32_t)(raw >> 32)), row);
+}
+
 // ---------------------------------------------------------------- row store statistics
 struct RowStatsParams {
     const float* rows; uint32_t ld; uint32_t dim;
@@ -123,6 +139,8 @@ uint32_t fused_tile_rows(int nqt);
 uint32_t fused_subpools_per_query(int nqt, uint32_t n_wg);
 // LDS-DMA variant of the headline shape (nqt = 8): same results, stages brought in by global_load_lds
 void launch_fused_dma(const FusedParams& p, uint32_t n_super, hipStream_t s);
+// three-image ring, barrier in the middle of a stage (kernels_fused_dma3.hip)
+void launch_fused_dma3(const FusedParams& p, uint32_t n_super, hipStream_t s);
 
 // ---------------------------------------------------------------- exact re-rank + certification
 struct RerankParams {

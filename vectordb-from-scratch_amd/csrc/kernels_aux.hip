@@ -323,7 +323,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 c[u] = (s0 + u < p.n_sub) ? sCnt[s0 + u] : 0u;
-                k[u] = (lane < c[u]) ? base[(size_t)(s0 + u) * p.capl + lane] : EMPTY_KEY;
+                k[u] = (lane < c[u]) ? raw_to_key(base[(size_t)(s0 + u) * p.capl + lane]) : EMPTY_KEY;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(NW * 64, 2) void fused_score_filter_kernel(FusedPar
         const float sc_ = fmaf(acc[i][4 * j + (E)], (AC), (BC));                                   \
         if (!(sc_ > thrq)) {                                                                       \
             const bool ok_ = (vbits >> (8 * j + (E))) & 1u;                                        \
-            if (pcnt < p.capl) mypool[pcnt] = ok_ ? make_key(sc_, rowb + 8 * j + (E)) : EMPTY_KEY; \
+            if (pcnt < p.capl) mypool[pcnt] = make_raw_key(sc_, ok_ ? rowb + 8 * j + (E) : 0xffffffffu); \
             ++pcnt;                                                                                \
         }                                                                                          \
     }

@@ -1,3 +1,7 @@
+// kernels_fused_dma3.hip -- three-image ring version of kernels_fused_dma.hip: the per-stage barrier sits in the
+// MIDDLE of a stage (it publishes stage s+1, whose LDS-DMA was issued a full stage earlier), so a wave runs
+// from the last MFMA group of stage s straight into stage s+1 (whose first fragments it has already read)
+// instead of draining the MFMA pipe at an end-of-stage barrier.
 // kernels_fused_dma.hip -- variant of the fused score+filter kernel whose K stages are brought into LDS
 // by LDS-DMA (`global_load_lds_dwordx4`: global memory -> LDS with no VGPR round trip and no ds_write),
 // for the headline shape only (8 waves, 128 rows x 256 queries).  Same MFMA sequence, K order, score
@@ -27,21 +31,21 @@ constexpr int ROWB = 128;                        // unpadded
 constexpr int A_BYTES = TR * ROWB;               // 16 KB
 constexpr int B_BYTES = 32 * NQT * ROWB;         // 32 KB
 constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 48 KB
-constexpr int NSTAGE = 2;
-constexpr int CONST_OFF = NSTAGE * STAGE_BYTES;
-constexpr int LDS_BYTES = CONST_OFF + 3 * TR * 4 * 2 + 3 * (TR / 32) * 4;
+
+
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 }  // namespace
 
-size_t fused_dma_lds_bytes() { return LDS_BYTES; }
 
-__global__ __launch_bounds__(NT, 2) void fused_score_filter_dma_kernel(FusedParams p) {
+__global__ __launch_bounds__(NT, 2) void fused_score_filter_dma3_kernel(FusedParams p) {
     // The two stage images are DISTINCT LDS objects and every access names its image at compile time
     // (the stage loop is unrolled by two): hipcc's waitcnt pass can then tell that a ds_read of one image
     // does not alias the LDS-DMA in flight into the other, and does not put a vmcnt(0) in front of it.
     __shared__ __attribute__((aligned(16))) char sImg0[STAGE_BYTES];
     __shared__ __attribute__((aligned(16))) char sImg1[STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char sImg2[STAGE_BYTES];
     __shared__ __attribute__((aligned(16))) float sAlpha[3 * TR];
     __shared__ __attribute__((aligned(16))) float sBeta[3 * TR];
     __shared__ uint32_t sValid[3 * (TR / 32)];
@@ -150,75 +154,77 @@ __global__ __launch_bounds__(NT, 2) void fused_score_filter_dma_kernel(FusedPara
     const uint32_t a_row_off = c * ROWB;                                // + i*32*ROWB
     const uint32_t b_row_off = A_BYTES + (qt * 32 + c) * ROWB;
 
-    // ---- prologue: stage 0 into image 0
-    VDB_TILE_OFFSETS(0u)
-    VDB_ISSUE(sImg0, 0u)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
+    // ---- prologue: stages 0 and 1 into images 0 and 1, published by one barrier
     uint32_t tile = 0, ks = 0;
     uint32_t otile = 0;                                                 // tile the DMA offsets currently describe
+    VDB_TILE_OFFSETS(0u)
+    VDB_ISSUE(sImg0, 0u)
+    if (total > 1) {
+        const uint32_t t1 = (KS == 1) ? 1u : 0u, k1 = (KS == 1) ? 0u : 1u;
+        if (t1 != otile) { VDB_TILE_OFFSETS(t1) otile = t1; }
+        VDB_ISSUE(sImg1, k1)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // fragments of K group 0 of the stage about to run are always read one stage ahead ("carried")
+    float4 fbC, faC[MT];
+    fbC = *reinterpret_cast<const float4*>(sImg0 + b_row_off + rd0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) faC[i] = *reinterpret_cast<const float4*>(sImg0 + a_row_off + i * 32 * ROWB + rd0);
+
     auto run_stage = [&](uint32_t st, auto partial_tag, auto buf_tag) {
         constexpr bool PARTIAL = decltype(partial_tag)::value;
         constexpr int BUF = decltype(buf_tag)::value;                   // LDS image this stage computes from
+        const char* img = BUF == 0 ? sImg0 : BUF == 1 ? sImg1 : sImg2;
+        const char* img_next = BUF == 0 ? sImg1 : BUF == 1 ? sImg2 : sImg0;     // stage st+1 (already landed)
+        char* img_fill = BUF == 0 ? sImg2 : BUF == 1 ? sImg0 : sImg1;           // stage st+2 goes here
         const uint32_t tr0 = r0 + tile * TR;
         const uint32_t mt_valid = PARTIAL ? ((r1 - tr0 + 31) >> 5) : (uint32_t)(TR / 32);
         uint32_t tile1 = tile, ks1 = ks + 1;
         if (ks1 == KS) { ks1 = 0; ++tile1; }
+        uint32_t tile2 = tile1, ks2 = ks1 + 1;
+        if (ks2 == KS) { ks2 = 0; ++tile2; }
         if (ks == 0) {                                                  // first stage of a tile: fetch its row constants
-            if (otile != tile) { VDB_TILE_OFFSETS(tile) otile = tile; }
-            VDB_LC()
+            const uint32_t cr_ = tile * TR + (tid % TR);
+            r_inrange_c = r0 + cr_ < r1;
+            const uint32_t rr_ = r0 + (r_inrange_c ? cr_ : rows_wg);
+            r_bit = rr_ & 31;
+            r_mask = p.rowmask[rr_ >> 5];
+            r_alpha = p.alpha[rr_];
+            r_beta = p.beta[rr_];
         }
-        if (st + 1 < total) {                                           // prefetch the next stage into the other image
-            if (otile != tile1) { VDB_TILE_OFFSETS(tile1) otile = tile1; }
-            if constexpr (BUF == 0) { VDB_ISSUE(sImg1, ks1) } else { VDB_ISSUE(sImg0, ks1) }
-        }
-
-        const char* sa = BUF == 0 ? sImg0 : sImg1;
-        const char* ap = sa + a_row_off;
-        const char* bp = sa + b_row_off;
-        if constexpr (!PARTIAL) {
-            float4 fbA, fbB, faA[MT], faB[MT];
-            fbA = *reinterpret_cast<const float4*>(bp + rd0);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) faA[i] = *reinterpret_cast<const float4*>(ap + i * 32 * ROWB + rd0);
-#define VDB_GROUP(RDN, FB, FA, FBN, FAN, LAST)                                                         \
-    {                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i] = VDB_MFMA(FA[i].x, FB.x, acc[i]);       \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i] = VDB_MFMA(FA[i].y, FB.y, acc[i]);       \
-        if constexpr (!(LAST)) {                                                                       \
-            FBN = *reinterpret_cast<const float4*>(bp + (RDN));                                        \
-            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                             \
-                FAN[i] = *reinterpret_cast<const float4*>(ap + i * 32 * ROWB + (RDN));                 \
-        }                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i] = VDB_MFMA(FA[i].z, FB.z, acc[i]);       \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) acc[i] = VDB_MFMA(FA[i].w, FB.w, acc[i]);       \
-    }
-            VDB_GROUP(rd1, fbA, faA, fbB, faB, false)
-            VDB_GROUP(rd2, fbB, faB, fbA, faA, false)
-            VDB_GROUP(rd3, fbA, faA, fbB, faB, false)
-            VDB_GROUP(0u, fbB, faB, fbA, faA, true)
-#undef VDB_GROUP
-        } else {
-            const uint32_t rd[4] = {rd0, rd1, rd2, rd3};
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 fb = *reinterpret_cast<const float4*>(bp + rd[g]);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    if ((uint32_t)i < mt_valid) {
-                        const float4 fa = *reinterpret_cast<const float4*>(ap + i * 32 * ROWB + rd[g]);
-                        acc[i] = VDB_MFMA(fa.x, fb.x, acc[i]);
-                        acc[i] = VDB_MFMA(fa.y, fb.y, acc[i]);
-                        acc[i] = VDB_MFMA(fa.z, fb.z, acc[i]);
-                        acc[i] = VDB_MFMA(fa.w, fb.w, acc[i]);
-                    }
-                }
-            }
-        }
-        if (ks == 0) { VDB_SC(tile) }                                   // the constant loads had a whole stage to land
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's DMA pieces of stage st+1 have landed
+        const char* ap = img + a_row_off;
+        const char* bp = img + b_row_off;
+        float4 fbB, faB[MT];
+#define VDB_MFMA4(FA, FB, COMP)                                                                        \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) if (!PARTIAL || (uint32_t)i < mt_valid) acc[i] = VDB_MFMA(FA[i].COMP, FB.COMP, acc[i]);
+#define VDB_READ(FB, FA, BASEA, BASEB, RD)                                                             \
+    FB = *reinterpret_cast<const float4*>((BASEB) + (RD));                                             \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i) FA[i] = *reinterpret_cast<const float4*>((BASEA) + i * 32 * ROWB + (RD));
+        // ---- K groups 0 and 1
+        VDB_MFMA4(faC, fbC, x) VDB_MFMA4(faC, fbC, y)
+        VDB_READ(fbB, faB, ap, bp, rd1)
+        VDB_MFMA4(faC, fbC, z) VDB_MFMA4(faC, fbC, w)
+        VDB_MFMA4(faB, fbB, x) VDB_MFMA4(faB, fbB, y)
+        VDB_READ(fbC, faC, ap, bp, rd2)
+        VDB_MFMA4(faB, fbB, z) VDB_MFMA4(faB, fbB, w)
+        // ---- mid-stage: publish stage st+1 (its DMA was issued one stage ago), then start stage st+2's DMA
+        if (ks == 0) { VDB_SC(tile) }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (st + 2 < total) {
+            if (otile != tile2) { VDB_TILE_OFFSETS(tile2) otile = tile2; }
+            VDB_ISSUE(img_fill, ks2)
+        }
+        // ---- K groups 2 and 3; the last one also reads group 0 of the next stage from its (published) image
+        VDB_MFMA4(faC, fbC, x) VDB_MFMA4(faC, fbC, y)
+        VDB_READ(fbB, faB, ap, bp, rd3)
+        VDB_MFMA4(faC, fbC, z) VDB_MFMA4(faC, fbC, w)
+        VDB_MFMA4(faB, fbB, x) VDB_MFMA4(faB, fbB, y)
+        if (st + 1 < total) { VDB_READ(fbC, faC, img_next + a_row_off, img_next + b_row_off, rd0) }
+        VDB_MFMA4(faB, fbB, z) VDB_MFMA4(faB, fbB, w)
+#undef VDB_MFMA4
+#undef VDB_READ
 
         if (ks == KS - 1) {
             const uint32_t par = tile % 3;
@@ -264,14 +270,20 @@ __global__ __launch_bounds__(NT, 2) void fused_score_filter_dma_kernel(FusedPara
     const uint32_t full_stages = full_tiles * KS;
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
+    using B2 = std::integral_constant<int, 2>;
     uint32_t st = 0;
-    for (; st + 1 < full_stages; st += 2) {                             // stage parity == image index
+    for (; st + 2 < full_stages; st += 3) {                             // stage index mod 3 == image index
         run_stage(st, std::false_type{}, B0{});
         run_stage(st + 1, std::false_type{}, B1{});
+        run_stage(st + 2, std::false_type{}, B2{});
     }
     for (; st < total; ++st) {
-        if (st < full_stages) { if (st & 1) run_stage(st, std::false_type{}, B1{}); else run_stage(st, std::false_type{}, B0{}); }
-        else { if (st & 1) run_stage(st, std::true_type{}, B1{}); else run_stage(st, std::true_type{}, B0{}); }
+        const uint32_t m = st % 3;
+        if (st < full_stages) {
+            if (m == 0) run_stage(st, std::false_type{}, B0{}); else if (m == 1) run_stage(st, std::false_type{}, B1{}); else run_stage(st, std::false_type{}, B2{});
+        } else {
+            if (m == 0) run_stage(st, std::true_type{}, B0{}); else if (m == 1) run_stage(st, std::true_type{}, B1{}); else run_stage(st, std::true_type{}, B2{});
+        }
     }
     p.pool_cnt[sub] = pcnt;
 #undef VDB_TILE_OFFSETS
@@ -281,8 +293,8 @@ __global__ __launch_bounds__(NT, 2) void fused_score_filter_dma_kernel(FusedPara
 #undef VDB_SC
 }
 
-void launch_fused_dma(const FusedParams& p, uint32_t n_super, hipStream_t s) {
-    hipLaunchKernelGGL(fused_score_filter_dma_kernel, dim3(p.n_wg, n_super), dim3(NT), 0, s, p);
+void launch_fused_dma3(const FusedParams& p, uint32_t n_super, hipStream_t s) {
+    hipLaunchKernelGGL(fused_score_filter_dma3_kernel, dim3(p.n_wg, n_super), dim3(NT), 0, s, p);
 }
 
 }  // namespace vdb

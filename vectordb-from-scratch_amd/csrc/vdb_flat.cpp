@@ -543,7 +543,9 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
                                 getenv("VDB_FUSED_ABLATE") ? (uint32_t)atoi(getenv("VDB_FUSED_ABLATE")) : 0u};
             if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
             static const bool use_dma = getenv("VDB_FUSED_REGSTAGE") == nullptr;   // default: LDS-DMA staging (VDB_FUSED_REGSTAGE=1: register-staged variant, same results)
-            if (use_dma && nqt == 8) vdb::launch_fused_dma(fp, n_super, s);
+            static const bool use_dma3 = getenv("VDB_FUSED_DMA2") == nullptr;   // default: 3-image ring with the barrier in mid-stage (VDB_FUSED_DMA2=1: 2-image variant)
+            if (use_dma && use_dma3 && nqt == 8) vdb::launch_fused_dma3(fp, n_super, s);
+            else if (use_dma && nqt == 8) vdb::launch_fused_dma(fp, n_super, s);
             else vdb::launch_fused(fp, nqt, n_super, s);
             if (ix->profile) {
                 // one super-tile per event pair: wait here so the pair can be reused (profiling mode only)
