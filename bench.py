@@ -205,6 +205,17 @@ def main():
                              f"(C restatement of the reference's single-threaded FlatIndex::search; the Rust reference "
                              f"cannot be built in this image)",
                    "host_cpus": os.cpu_count(), "ids_and_distances_bit_identical": exact}
+            # second, clearly separate row: the same port on several cores, one whole query
+            # per thread (the reference itself is single-threaded on this path; ctypes releases the GIL)
+            import concurrent.futures
+            nthr = int(min(16, os.cpu_count() or 1, B))
+            t1 = time.perf_counter()
+            with concurrent.futures.ThreadPoolExecutor(nthr) as ex:
+                list(ex.map(lambda b: oracle.flat_search(args.metric, rows_host, q_host[b], k, live=live_host),
+                            range(nthr)))
+            t_mt = time.perf_counter() - t1
+            cpu["all_cores_row"] = {"value": round(nthr / t_mt, 3), "unit": "queries/s", "cores": nthr,
+                                    "sample": f"{nthr} queries, one per thread, {t_mt:.1f} s"}
         else:
             parity_n = {"queries_checked_against_oracle": done, "ids_and_distances_bit_identical": exact}
 

@@ -134,6 +134,16 @@ int vdb_flat_search_batch_device(vdb_flat_index *h, const float *d_queries, size
                                  void *stream);
 
 /*
+ * DistanceMetric::distance (src/distance.rs:20-33) for explicit (query, stored id) pairs, batched: the
+ * candidate-list distance evaluations of an HNSW search (src/hnsw/graph.rs:155, :182 -- BASELINE config 5),
+ * computed on the GPU in the reference's operation order (bit-identical to the CPU).  Query b is paired with
+ * ids[offsets[b] .. offsets[b+1]); out_dists has offsets[nq] entries; an id that is not stored gives NaN.
+ * Zero norm on either side under Cosine -> VDB_ERR_INVALID_VECTOR (distance.rs:51-55).
+ */
+int vdb_flat_distances_batch(vdb_flat_index *h, const float *queries, size_t nq, size_t dim,
+                             const size_t *offsets, const uint64_t *ids, float *out_dists);
+
+/*
  * Multi-GPU exchange step: merge `nparts` partial top-k lists per query
  * (gathered from the row shards with an RCCL all-gather) into the global
  * top-k, ascending by (distance, id).  All pointers are device pointers on
@@ -143,6 +153,13 @@ int vdb_merge_topk_device(int device, const uint64_t *d_part_ids, const float *d
                           const uint32_t *d_part_counts, size_t nparts, size_t nq, size_t k,
                           uint64_t *d_out_ids, float *d_out_dists, uint32_t *d_out_counts,
                           void *stream);
+
+/* The same merge reading the all-gathered exchange buffer in place.  Each part is `words_per_part` int32
+ * words (even): ids int64[nq*k] | dists f32[nq*k] | counts i32[nq] | status i32 | pad.  *d_out_status (may be
+ * NULL) receives the maximum status word over the parts, so one host read tells whether any shard failed. */
+int vdb_merge_topk_packed_device(int device, const int32_t *d_packed, size_t nparts, size_t words_per_part,
+                                 size_t nq, size_t k, uint64_t *d_out_ids, float *d_out_dists,
+                                 uint32_t *d_out_counts, uint32_t *d_out_status, void *stream);
 
 /* Measurement hook for bench.py: when on, every search brackets its fused MFMA kernel launch
  * with HIP events on the launch stream and vdb_flat_last_stats()[7] reports the kernel's

@@ -329,3 +329,31 @@ def test_concurrent_searches_from_several_threads(vdb):
     [t.join() for t in ts]
     for w, g in zip(want, got):
         assert all(np.array_equal(a, b) for a, b in zip(w, g))
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_candidate_list_distances_match_reference(vdb, metric):
+    """BASELINE config 5's offload unit: distances of a query to explicit candidate lists (the calls an
+    HNSW search_layer makes, src/hnsw/graph.rs:155,:182), bit-identical to DistanceMetric::distance."""
+    rng = np.random.default_rng(31 + metric)
+    n, d = 5000, 77
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    ids = rng.permutation(np.arange(100, 100 + n)).astype(np.uint64)
+    ix = make_index(vdb, metric, rows, ids)
+    queries = rng.standard_normal((9, d)).astype(np.float32)
+    lists = [rng.choice(ids, size=rng.integers(0, 33), replace=False) for _ in range(9)]   # <= 2m = 32 per expansion
+    lists[3] = np.array([ids[0], np.uint64(10 ** 12)], dtype=np.uint64)                 # an id that is not stored
+    got = ix.distances_batch(queries, lists)
+    row_of = {int(v): i for i, v in enumerate(ids)}
+    for b, (l, g) in enumerate(zip(lists, got)):
+        assert len(g) == len(l)
+        for j, vid in enumerate(l):
+            if int(vid) in row_of:
+                want = oracle.distance(metric, queries[b], rows[row_of[int(vid)]])
+                assert np.float32(g[j]).view(np.uint32) == np.float32(want).view(np.uint32)
+            else:
+                assert np.isnan(g[j])
+    if metric == 1:
+        ix.add(7, vdb.Vector(np.zeros(d, np.float32)))
+        with pytest.raises(vdb.InvalidVector):
+            ix.distances_batch(queries[:1], [[7]])

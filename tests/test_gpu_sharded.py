@@ -44,3 +44,42 @@ def test_shards_merge_equals_unsharded(metric, world):
     for b in range(0, B, 5):
         oi, od = oracle.flat_search(metric, rows, queries[b], k)
         assert np.array_equal(mi[b].cpu().numpy().astype(np.uint64), oi) and np.array_equal(md[b].cpu().numpy(), od)
+
+
+def test_packed_exchange_buffer_merge():
+    """vdb_merge_topk_packed_device reads the all-gathered buffer of sharded.py in place and reduces the status words."""
+    import ctypes
+    vdb = load_package()
+    vdb.build()
+    from vectordb_from_scratch_amd import _ffi
+    from vectordb_from_scratch_amd.sharded import merge_topk_torch
+    W, B, k = 3, 17, 10
+    g = torch.Generator().manual_seed(5)
+    words = B * (3 * k + 1) + 1
+    words += words & 1
+    dev = torch.device("cuda", 0)
+    ids = torch.randint(0, 1000, (W, B, k), generator=g, dtype=torch.int64)
+    dists = torch.rand((W, B, k), generator=g).sort(dim=2).values
+    dists[1, :, 3] = dists[0, :, 3]                                   # cross-part distance ties -> decided by id
+    counts = torch.randint(0, k + 1, (W, B), generator=g, dtype=torch.int32)
+    packed = torch.zeros((W, words), dtype=torch.int32)
+    for w in range(W):
+        packed[w, :2 * B * k] = ids[w].contiguous().view(torch.int32).view(-1)
+        packed[w, 2 * B * k:3 * B * k] = dists[w].contiguous().view(torch.int32).view(-1)
+        packed[w, 3 * B * k:3 * B * k + B] = counts[w]
+        packed[w, 3 * B * k + B] = w                                  # status words 0, 1, 2 -> max 2
+    pd = packed.to(dev)
+    out_i = torch.empty((B, k), dtype=torch.int64, device=dev)
+    out_d = torch.empty((B, k), dtype=torch.float32, device=dev)
+    out_c = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    rc = _ffi.lib().vdb_merge_topk_packed_device(0, ctypes.c_void_p(pd.data_ptr()), W, words, B, k,
+                                                 ctypes.c_void_p(out_i.data_ptr()), ctypes.c_void_p(out_d.data_ptr()),
+                                                 ctypes.c_void_p(out_c.data_ptr()), ctypes.c_void_p(out_c.data_ptr() + 4 * B), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    ti, td, tc = merge_topk_torch(ids, dists, counts, k)
+    n = tc.tolist()
+    assert out_c[:B].cpu().tolist() == n and int(out_c[B]) == 2
+    for b in range(B):
+        assert out_i[b, :n[b]].cpu().tolist() == ti[b, :n[b]].tolist()
+        assert torch.equal(out_d[b, :n[b]].cpu(), td[b, :n[b]])

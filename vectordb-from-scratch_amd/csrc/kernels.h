@@ -210,4 +210,17 @@ void launch_merge_parts(const uint64_t* ids, const float* dists, const uint32_t*
                         uint32_t nq, uint32_t k, uint64_t* out_ids, float* out_dists, uint32_t* out_counts,
                         hipStream_t s);
 
+// ---------------------------------------------------------------- candidate-list distances (HNSW offload hook)
+struct PairDistParams {
+    const float* rows; uint32_t ld; uint32_t dim;
+    const float* qp; const float* qnorm; const float* nd;
+    const uint32_t* pair_query; const uint32_t* pair_row; uint32_t n_pairs;   // pair_row 0xffffffff = unknown id
+    int metric;
+    float* out; uint32_t* status;                                            // ST_NAN / ST_ZERO_QUERY (zero norm on either side)
+};
+void launch_pair_distances(const PairDistParams& p, hipStream_t s);
+
+void launch_merge_packed(const int32_t* packed, size_t words_per_part, uint32_t nparts, uint32_t nq, uint32_t k,
+                         uint64_t* out_ids, float* out_dists, uint32_t* out_counts, uint32_t* out_status, hipStream_t s);
+
 }  // namespace vdb

@@ -749,11 +749,36 @@ void launch_emit(const EmitParams& p, hipStream_t s) {
 // Multi-GPU exchange: merge nparts sorted partial top-k lists per query by (distance, id).
 // One workgroup per query; nparts*k <= 2048 candidates sorted in LDS.
 // ---------------------------------------------------------------------------------------------
+// DistanceMetric::distance for explicit (query, stored row) pairs: what an HNSW search_layer asks for at
+// src/hnsw/graph.rs:155 and :182 (at most 2m = 32 neighbours per expansion), batched over many queries.
+__global__ __launch_bounds__(256) void pair_distances_kernel(PairDistParams p) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n_pairs) return;
+    const uint32_t row = p.pair_row[i], q = p.pair_query[i];
+    float d = __uint_as_float(0x7fc00000u);
+    if (row != 0xffffffffu) {
+        const float qn = p.qnorm[q], xn = p.nd[row];
+        if (p.metric == COSINE && (qn == 0.0f || xn == 0.0f)) atomicOr(p.status, ST_ZERO_QUERY);
+        d = exact_distance(p.metric, p.qp + (size_t)q * p.ld, p.rows + (size_t)row * p.ld, p.dim, qn, xn);
+        if (d != d) atomicOr(p.status, ST_NAN);
+    }
+    p.out[i] = d;
+}
+void launch_pair_distances(const PairDistParams& p, hipStream_t s) {
+    if (!p.n_pairs) return;
+    hipLaunchKernelGGL(pair_distances_kernel, dim3((p.n_pairs + 255) / 256), dim3(256), 0, s, p);
+}
+
 constexpr uint32_t MERGE_MAX = 2048;
+// part p's arrays start at ids + p*ids_stride, dists + p*dists_stride, counts + p*counts_stride (element units),
+// so both the plain [nparts][nq][k] layout and the packed all-gather buffer of sharded.py can be merged in place
 __global__ __launch_bounds__(256) void merge_parts_kernel(const uint64_t* ids, const float* dists,
-                                                          const uint32_t* counts, uint32_t nparts, uint32_t nq,
+                                                          const uint32_t* counts, size_t ids_stride,
+                                                          size_t dists_stride, size_t counts_stride,
+                                                          const uint32_t* status, size_t status_stride,
+                                                          uint32_t nparts, uint32_t nq,
                                                           uint32_t k, uint64_t* out_ids, float* out_dists,
-                                                          uint32_t* out_counts) {
+                                                          uint32_t* out_counts, uint32_t* out_status) {
     __shared__ uint32_t sD[MERGE_MAX];
     __shared__ uint64_t sI[MERGE_MAX];
     __shared__ uint32_t sTotal;
@@ -762,6 +787,11 @@ __global__ __launch_bounds__(256) void merge_parts_kernel(const uint64_t* ids, c
     uint32_t P = 2;
     while (P < total) P <<= 1;
     if (tid == 0) sTotal = 0;
+    if (q == 0 && tid == 0 && out_status) {
+        uint32_t worst = 0;
+        for (uint32_t part = 0; part < nparts; ++part) { uint32_t v = status[part * status_stride]; worst = v > worst ? v : worst; }
+        *out_status = worst;
+    }
     __syncthreads();
     uint32_t mine = 0;
     for (uint32_t i = tid; i < P; i += 256) {
@@ -769,10 +799,9 @@ __global__ __launch_bounds__(256) void merge_parts_kernel(const uint64_t* ids, c
         uint64_t id = ~0ull;
         if (i < total) {
             uint32_t part = i / k, j = i - part * k;
-            if (j < counts[(size_t)part * nq + q]) {
-                size_t o = ((size_t)part * nq + q) * k + j;
-                od = f32_to_ordered(dists[o]);
-                id = ids[o];
+            if (j < counts[part * counts_stride + q]) {
+                od = f32_to_ordered(dists[part * dists_stride + (size_t)q * k + j]);
+                id = ids[part * ids_stride + (size_t)q * k + j];
                 ++mine;
             }
         }
@@ -807,8 +836,20 @@ void launch_merge_parts(const uint64_t* ids, const float* dists, const uint32_t*
                         uint32_t nq, uint32_t k, uint64_t* out_ids, float* out_dists, uint32_t* out_counts,
                         hipStream_t s) {
     if (!nq || !k) return;
-    hipLaunchKernelGGL(merge_parts_kernel, dim3(nq), dim3(256), 0, s, ids, dists, counts, nparts, nq, k,
-                       out_ids, out_dists, out_counts);
+    hipLaunchKernelGGL(merge_parts_kernel, dim3(nq), dim3(256), 0, s, ids, dists, counts, (size_t)nq * k, (size_t)nq * k,
+                       (size_t)nq, nullptr, (size_t)0, nparts, nq, k, out_ids, out_dists, out_counts, nullptr);
+}
+// packed layout of one part (int32 words): ids int64[nq*k] | dists f32[nq*k] | counts i32[nq] | status i32 | pad
+void launch_merge_packed(const int32_t* packed, size_t words_per_part, uint32_t nparts, uint32_t nq, uint32_t k,
+                         uint64_t* out_ids, float* out_dists, uint32_t* out_counts, uint32_t* out_status,
+                         hipStream_t s) {
+    if (!nq || !k) return;
+    const size_t nk = (size_t)nq * k;
+    hipLaunchKernelGGL(merge_parts_kernel, dim3(nq), dim3(256), 0, s, reinterpret_cast<const uint64_t*>(packed),
+                       reinterpret_cast<const float*>(packed + 2 * nk), reinterpret_cast<const uint32_t*>(packed + 3 * nk),
+                       words_per_part / 2, words_per_part, words_per_part,
+                       reinterpret_cast<const uint32_t*>(packed + 3 * nk + nq), words_per_part, nparts, nq, k, out_ids,
+                       out_dists, out_counts, out_status);
 }
 
 }  // namespace vdb

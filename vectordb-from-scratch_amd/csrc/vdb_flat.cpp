@@ -968,6 +968,75 @@ int vdb_merge_topk_device(int device, const uint64_t* d_part_ids, const float* d
     return VDB_OK;
 }
 
+int vdb_flat_distances_batch(vdb_flat_index* ix, const float* queries, size_t nq, size_t dim, const size_t* offsets,
+                             const uint64_t* ids, float* out_dists) {
+    if (!ix || !offsets || (nq && !queries)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t total = offsets[nq];
+    if (total && (!ids || !out_dists)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc = set_device(ix);
+    if (rc) return rc;
+    if ((rc = flush(ix))) return rc;
+    if (total == 0) return VDB_OK;
+    if (total > 0xfffffff0ull || nq > 0x7fffffffull) return fail(VDB_ERR_INVALID_ARGUMENT, "too many pairs");
+    // distance.rs:21-26: a stored row of another dimension fails the call
+    for (size_t i = 0; i < total; ++i) {
+        auto m = ix->misfits.find(ids[i]);
+        if (m != ix->misfits.end() && m->second.size() != dim) return fail_dim(dim, m->second.size());
+    }
+    if (ix->n_live && ix->dim != dim) return fail_dim(dim, ix->dim);
+    hipStream_t s = ix->stream;
+    const uint32_t ld = ix->ld ? ix->ld : round_up((uint32_t)dim, vdb::KSTAGE);
+    const uint32_t nq32 = (uint32_t)nq, bp = round_up(nq32, SUPER);
+    std::vector<uint32_t> prow(total), pq(total);
+    for (uint32_t q = 0; q < nq32; ++q)
+        for (size_t i = offsets[q]; i < offsets[q + 1]; ++i) {
+            auto it = ix->id2row.find(ids[i]);
+            prow[i] = it == ix->id2row.end() ? 0xffffffffu : it->second;
+            pq[i] = q;
+        }
+    if ((rc = ix->w_qin.ensure(nq * dim))) return rc;
+    if ((rc = ix->w_qp.ensure((size_t)bp * ld))) return rc;
+    if ((rc = ix->w_qnorm.ensure(bp))) return rc;
+    if ((rc = ix->w_thr.ensure(bp))) return rc;
+    if ((rc = ix->w_flags.ensure(4))) return rc;
+    if ((rc = ix->w_rowmask.ensure(2 * total))) return rc;      // pair_row | pair_query
+    if ((rc = ix->w_outd.ensure(total))) return rc;
+    HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, 16, s));
+    HIP_TRY(hipMemcpyAsync(ix->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ix->w_rowmask.p, prow.data(), total * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ix->w_rowmask.p + total, pq.data(), total * 4, hipMemcpyHostToDevice, s));
+    vdb::QueryPrepParams qp{ix->w_qin.p, (uint32_t)dim, nq32, ix->w_qp.p, ld, bp, ix->w_qnorm.p, ix->w_thr.p, vdb::EUCLID,
+                            ix->w_flags.p};   // metric EUCLID here: zero norms are judged per PAIR below
+    vdb::launch_query_prep(qp, s);
+    vdb::PairDistParams pp{ix->d_rows, ld, (uint32_t)dim, ix->w_qp.p, ix->w_qnorm.p, ix->d_nd, ix->w_rowmask.p + total,
+                           ix->w_rowmask.p, (uint32_t)total, ix->metric, ix->w_outd.p, ix->w_flags.p};
+    vdb::launch_pair_distances(pp, s);
+    HIP_TRY(hipGetLastError());
+    uint32_t st = 0;
+    HIP_TRY(hipMemcpyAsync(out_dists, ix->w_outd.p, total * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&st, ix->w_flags.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (st & vdb::ST_ZERO_QUERY)
+        return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
+    return VDB_OK;   // a NaN distance is returned as NaN (only the sort in FlatIndex::search panics on it)
+}
+
+int vdb_merge_topk_packed_device(int device, const int32_t* d_packed, size_t nparts, size_t words_per_part, size_t nq,
+                                 size_t k, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
+                                 uint32_t* d_out_status, void* stream) {
+    if (!d_packed || !d_out_ids || !d_out_dists || !d_out_counts)
+        return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    if (nparts * k > 2048) return fail(VDB_ERR_INVALID_ARGUMENT, "nparts*k = %zu exceeds 2048", nparts * k);
+    if ((words_per_part & 1) || words_per_part < nq * (3 * k + 1) + 1)
+        return fail(VDB_ERR_INVALID_ARGUMENT, "words_per_part must be even and >= nq*(3k+1)+1");
+    HIP_TRY(hipSetDevice(device));
+    vdb::launch_merge_packed(d_packed, words_per_part, (uint32_t)nparts, (uint32_t)nq, (uint32_t)k, d_out_ids,
+                             d_out_dists, d_out_counts, d_out_status, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return VDB_OK;
+}
+
 int vdb_flat_set_profile(vdb_flat_index* ix, int on) {
     if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
     std::lock_guard<std::mutex> g(ix->mu);

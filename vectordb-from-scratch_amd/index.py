@@ -220,6 +220,21 @@ class GpuFlatIndex(Index):
         if rc:
             _raise(rc)
 
+    def distances_batch(self, queries, id_lists):
+        """Exact reference distances of query b to the stored ids id_lists[b] (HNSW candidate lists)."""
+        qs = np.ascontiguousarray(queries, dtype=np.float32)
+        nq, dim = qs.shape
+        offsets = np.zeros(nq + 1, dtype=np.uintp)
+        offsets[1:] = np.cumsum([len(l) for l in id_lists])
+        ids = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.uint64) for l in id_lists])
+                                   if int(offsets[-1]) else np.zeros(0, np.uint64))
+        out = np.zeros(int(offsets[-1]), dtype=np.float32)
+        rc = self._L.vdb_flat_distances_batch(self._h, _fp(qs), nq, dim,
+                                              offsets.ctypes.data_as(ctypes.POINTER(ctypes.c_size_t)), _u64p(ids), _fp(out))
+        if rc:
+            _raise(rc)
+        return [out[int(offsets[b]):int(offsets[b + 1])] for b in range(nq)]
+
     def last_stats(self):
         out = (ctypes.c_uint64 * 8)()
         self._L.vdb_flat_last_stats(self._h, out)

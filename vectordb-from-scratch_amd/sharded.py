@@ -115,12 +115,26 @@ class ShardedSearcher:
         pk[words - 1] = code
         dist.all_gather_into_tensor(self._gath, pk, group=self.group)
         g = self._gath.view(self.world, pk.numel())
-        g_ids = g[:, :2 * B * k].contiguous().view(torch.int64).view(self.world, B, k)
-        g_d = g[:, 2 * B * k:3 * B * k].contiguous().view(torch.float32).view(self.world, B, k)
-        g_cnt = g[:, 3 * B * k:3 * B * k + B].contiguous()
-        merge = self.merge or (merge_topk_hip if ids.is_cuda else merge_topk_torch)
-        out = merge(g_ids, g_d, g_cnt, k)                 # enqueue the merge first, then ONE host sync for the status
-        worst = int(g[:, words - 1].max().item())
+        if ids.is_cuda and self.merge is None:
+            # merge straight out of the gathered buffer; the kernel also reduces the status words
+            out_i = torch.empty((B, k), dtype=torch.int64, device=ids.device)
+            out_d = torch.empty((B, k), dtype=torch.float32, device=ids.device)
+            out_c = torch.empty((B + 1,), dtype=torch.int32, device=ids.device)      # [B] = worst status
+            rc = _ffi.lib().vdb_merge_topk_packed_device(
+                ids.device.index or 0, ctypes.c_void_p(self._gath.data_ptr()), self.world, pk.numel(), B, k,
+                ctypes.c_void_p(out_i.data_ptr()), ctypes.c_void_p(out_d.data_ptr()), ctypes.c_void_p(out_c.data_ptr()),
+                ctypes.c_void_p(out_c.data_ptr() + 4 * B), ctypes.c_void_p(torch.cuda.current_stream(ids.device).cuda_stream))
+            if rc:
+                raise IndexError_(_ffi.last_error()[0])
+            out = (out_i, out_d, out_c[:B])
+            worst = int(out_c[B].item())                  # the ONE host sync of the exchange
+        else:
+            g_ids = g[:, :2 * B * k].contiguous().view(torch.int64).view(self.world, B, k)
+            g_d = g[:, 2 * B * k:3 * B * k].contiguous().view(torch.float32).view(self.world, B, k)
+            g_cnt = g[:, 3 * B * k:3 * B * k + B].contiguous()
+            merge = self.merge or merge_topk_torch
+            out = merge(g_ids, g_d, g_cnt, k)
+            worst = int(g[:, words - 1].max().item())
         if worst:
             if err:
                 raise err
