@@ -26,7 +26,7 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build the HIP extension first (python -m vectordb-from-scratch_amd/build.py "
+            f"{LIB_PATH} is missing: build the HIP extension first (python vectordb-from-scratch_amd/build.py "
             "or __graft_entry__.build()); this engine has no CPU fallback")
     L = ctypes.CDLL(LIB_PATH)
     c = ctypes

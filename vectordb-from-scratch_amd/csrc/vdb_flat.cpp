@@ -360,8 +360,7 @@ uint32_t pick_kp(size_t k) {
 
 // ------------------------------------------------------------------ exact path for one query
 int exact_one(Index* ix, hipStream_t s, uint32_t q, size_t k, const uint32_t* d_rowmask, uint64_t* d_out_ids,
-              float* d_out_dists, uint32_t* d_out_count, float qnorm_unused) {
-    (void)qnorm_unused;
+              float* d_out_dists, uint32_t* d_out_count) {
     int rc;
     uint32_t n = ix->n_uploaded;
     if ((rc = ensure_ranks(ix))) return rc;
@@ -474,7 +473,7 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
             return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
         for (uint32_t q = 0; q < nq32; ++q) {
             if ((rc = exact_one(ix, s, q, k, d_rowmask, d_out_ids + (size_t)q * k, d_out_dists + (size_t)q * k,
-                                d_out_counts + q, 0.f)))
+                                d_out_counts + q)))
                 return rc;
         }
         ix->stats[1] = nq32;
@@ -629,7 +628,7 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
         }
         for (uint32_t q : dense)
             if ((rc = exact_one(ix, s, q, k, d_rowmask, d_out_ids + (size_t)q * k, d_out_dists + (size_t)q * k,
-                                d_out_counts + q, 0.f)))
+                                d_out_counts + q)))
                 return rc;
     }
     ix->stats[0] = nq32 - n_fallback;
