@@ -357,3 +357,26 @@ def test_candidate_list_distances_match_reference(vdb, metric):
         ix.add(7, vdb.Vector(np.zeros(d, np.float32)))
         with pytest.raises(vdb.InvalidVector):
             ix.distances_batch(queries[:1], [[7]])
+
+
+@pytest.mark.parametrize("n,d,nq,k,metric", [
+    (16384, 32, 33, 10, 0),     # largest index still on the dense path
+    (16385, 32, 33, 10, 1),     # smallest index on the fused path: 2 blocks of 32 rows per workgroup
+    (16511, 1, 5, 3, 2),        # dimension 1 (K padded 1 -> 32)
+    (17000, 2, 129, 10, 0),     # 129 queries: 8-wave shape with 127 padding queries
+    (17000, 31, 255, 1, 1),
+    (20000, 33, 257, 10, 2),    # two passes: 256 queries + 1 query (32-query shape)
+    (24000, 100, 64, 10, 0),    # exactly the 64-query shape
+    (24000, 100, 65, 10, 1),    # 128-query shape with padding
+    (33000, 7, 128, 32, 2),     # k = 32 -> kp = 64
+    (40000, 16, 31, 26, 0),     # k + slack == 32 boundary
+    (40000, 16, 31, 27, 0),     # first k that needs kp = 64
+])
+def test_shape_boundaries(vdb, n, d, nq, k, metric):
+    rng = np.random.default_rng(n + 13 * d + nq)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    ix = check_against_oracle(vdb, metric, rows, q, k, qsel=sorted({0, nq // 2, nq - 1}))
+    st = ix.last_stats()
+    assert st["pool_overflows"] == 0, st
+    assert (st["rows_scanned"] > 0) == (n > 16384), st
