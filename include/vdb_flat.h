@@ -173,6 +173,20 @@ int vdb_flat_set_profile(vdb_flat_index *h, int on);
  *  [6] uncertified queries                 [7] fused-kernel time of the search, ns (profiling on) */
 int vdb_flat_last_stats(const vdb_flat_index *h, uint64_t out[8]);
 
+/* The same counters followed by (n up to 16, the rest reads 0):
+ *  [8] 1 when the bf16 screening tier answered the batch first, 0 when only the f32 MFMA tier ran
+ *  [9] queries the screening tier could not certify and handed to the f32 MFMA tier
+ * With the screening tier on, [4] [5] [7] describe ITS sample, k' and kernel time. */
+int vdb_flat_last_stats_ex(const vdb_flat_index *h, uint64_t *out, size_t n);
+
+/* Tier selection for indexes above 16384 rows (no reference counterpart; results are identical either way):
+ *  1 (default): a first pass ranks every row on the bf16 matrix cores (HBM-bound), keeps k' candidates per
+ *     query, re-ranks them with the reference's exact f32 arithmetic (distance.rs:37-73) and certifies the
+ *     result with a rigorous bound on the bf16 rounding error; uncertified queries go to the f32 tier;
+ *  0: the f32-input MFMA tier only (v_mfma_f32_32x32x2_f32, arithmetic-bound), then the exact scan.
+ * The environment variable VDB_SCREEN=f32 selects 0 for every handle created afterwards. */
+int vdb_flat_set_screen(vdb_flat_index *h, int mode);
+
 /* Thread-local message of the last failing call on this thread, plus the
  * DimensionMismatch pair (error.rs:12-13).  Any pointer may be NULL. */
 void vdb_last_error(char *buf, size_t cap, size_t *expected, size_t *actual);

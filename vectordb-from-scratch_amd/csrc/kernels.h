@@ -66,7 +66,8 @@ struct RowStatsParams {
     float* nd;        // exact-order norm  sqrt(fold(x*x))      (vector.rs:35-37)
     float* alpha;     // score = fma(dot, alpha, beta)
     float* beta;
-    uint32_t* nd2max_bits;   // atomicMax of the f32 bits of fold(x*x)
+    uint32_t* nd2max_bits;   // atomicMax of the f32 bits of fold(x*x); [2] / [3]: max of the bf16 rounding error of a
+                             // row, as f32 bits of |x - bf16(x)|^2 (slot 2) and of |x - bf16(x)|^2 / |x|^2 (slot 3)
 };
 void launch_row_stats(const RowStatsParams& p, hipStream_t s);
 
@@ -86,6 +87,8 @@ struct QueryPrepParams {
     float* thr;                                        // padding queries get -inf here (nothing passes)
     int metric;
     uint32_t* status;
+    uint16_t* qb;                                      // may be null: [nq_pad][ld] bf16 (RNE) copy for the screening tier
+    float* qerr;                                       // with qb: |q - bf16(q)| per query (upper bound)
 };
 void launch_query_prep(const QueryPrepParams& p, hipStream_t s);
 
@@ -142,6 +145,33 @@ void launch_fused_dma(const FusedParams& p, uint32_t n_super, hipStream_t s);
 // three-image ring, barrier in the middle of a stage (kernels_fused_dma3.hip)
 void launch_fused_dma3(const FusedParams& p, uint32_t n_super, hipStream_t s);
 
+// ---------------------------------------------------------------- bf16 screening tier (kernels_fused_bf16.hip)
+struct FusedBf16Params {
+    const float* rows; uint32_t ld; uint32_t n_rows;
+    const uint16_t* qb;                                // [256][ld] bf16 queries of this pass (zero padded)
+    const float* alpha; const float* beta;
+    const uint32_t* rowmask;                           // NEVER null: the live mask when there is no filter
+    // filter mode: keys with score <= thr[q] go to the private sub-pool
+    //   sub = ((q*n_wg + range)*2 + row half)*2 + lane half ; keys at pool[sub*capl ..], count at pool_cnt[sub]
+    const float* thr;                                  // [256]
+    uint64_t* pool; uint32_t* pool_cnt; uint32_t capl;
+    uint32_t n_wg;                                     // row ranges = grid.x
+    // sample mode: sample j -> row j*n_rows/n_sample; per query and group of 64 sample rows the smallest key
+    uint32_t n_sample; uint64_t* minkeys; uint32_t minkey_stride;   // minkeys[q*minkey_stride + group]
+};
+void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s);
+void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s);
+uint32_t fused_bf16_tile_rows();
+uint32_t fused_bf16_subpools_per_query(uint32_t n_wg);
+uint32_t fused_bf16_sample_groups(uint32_t n_sample);
+
+// compact re-run of uncertified queries: gather padded query rows / norms, scatter results back
+void launch_gather_queries(const float* qp, const float* qnorm, uint32_t ld, const uint32_t* qidx, uint32_t n,
+                           uint32_t n_pad, float* qp_out, float* qnorm_out, float* thr_out, hipStream_t s);
+void launch_scatter_results(const uint64_t* ids, const float* dists, const uint32_t* counts, const uint32_t* qidx,
+                            uint32_t n, uint32_t k, uint64_t* out_ids, float* out_dists, uint32_t* out_counts,
+                            hipStream_t s);
+
 // ---------------------------------------------------------------- exact re-rank + certification
 struct RerankParams {
     const float* rows; uint32_t ld; uint32_t dim; uint32_t n_rows;
@@ -156,6 +186,11 @@ struct RerankParams {
     uint64_t* out_ids; float* out_dists; uint32_t* out_counts; uint32_t out_stride;
     uint32_t* cert;                                    // [nq]: 1 = certified exact
     uint32_t* status;
+    const float* thr;                                  // may be null: the filter threshold the candidates passed; a short
+                                                       // candidate list under a FINITE threshold is never certified
+    const float* qerr; float c_acc;                    // bf16 screening tier (qerr != null): |q - bf16(q)| per query and the
+                                                       // MFMA accumulation coefficient; the row-side error maxima are
+                                                       // nd2max_bits[2] and [3]
     uint32_t lds_row_stride, lds_chunk;                // filled by launch_rerank
 };
 void launch_rerank(const RerankParams& p, uint32_t nq, hipStream_t s);

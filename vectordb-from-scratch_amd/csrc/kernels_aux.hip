@@ -104,11 +104,15 @@ __device__ __forceinline__ float exact_distance(int metric, const float* __restr
 // Row statistics at upload: exact-order norm and the (alpha, beta) of the ranking score
 //   score = fma(dot, alpha, beta):  Euclid  nd2 - 2 dot ; Cosine  -dot/|d| ; Dot  -dot
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_round(float v) {        // the value v_cvt_pk_bf16_f32 (RNE) keeps
+    return __uint_as_float((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)v) << 16);
+}
 __global__ __launch_bounds__(256) void row_stats_kernel(RowStatsParams p) {
     uint32_t row = p.row_begin + blockIdx.x * blockDim.x + threadIdx.x;
-    float nd2 = 0.0f;
+    float nd2 = 0.0f, e2 = 0.0f, rel2 = 0.0f;
     if (row < p.row_end) {
-        nd2 = fold_sq(p.rows + (size_t)row * p.ld, p.dim);
+        const float* x = p.rows + (size_t)row * p.ld;
+        nd2 = fold_sq(x, p.dim);
         float nd = __builtin_sqrtf(nd2);
         p.nd[row] = nd;
         float a, b;
@@ -117,11 +121,25 @@ __global__ __launch_bounds__(256) void row_stats_kernel(RowStatsParams p) {
         else { a = -1.0f; b = 0.0f; }
         p.alpha[row] = a;
         p.beta[row] = b;
+        // bf16 rounding error of the row (screening-tier certification): |x - bf16(x)|^2, rounded up a little
+        for (uint32_t i = 0; i < p.dim; ++i) { float e = x[i] - bf16_round(x[i]); e2 += e * e; }
+        e2 *= 1.0001f;
+        rel2 = nd2 > 0.0f ? e2 / nd2 * 1.0001f : 0.0f;
+        if (!(e2 == e2)) e2 = 0.0f;                    // NaN / inf rows are caught by the NaN status, not by this bound
+        if (!(rel2 == rel2)) rel2 = 0.0f;
     }
     // wave max of the (non-negative or NaN) bit patterns, one atomic per wave
-    uint32_t bits = __float_as_uint(nd2) & 0x7fffffffu;
-    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_xor(bits, o); bits = t > bits ? t : bits; }
-    if ((threadIdx.x & 63) == 0 && bits) atomicMax(p.nd2max_bits, bits);
+    uint32_t bits = __float_as_uint(nd2) & 0x7fffffffu, be = __float_as_uint(e2), br = __float_as_uint(rel2);
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t t = __shfl_xor(bits, o); bits = t > bits ? t : bits;
+        t = __shfl_xor(be, o); be = t > be ? t : be;
+        t = __shfl_xor(br, o); br = t > br ? t : br;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bits) atomicMax(p.nd2max_bits, bits);
+        if (be) atomicMax(p.nd2max_bits + 2, be);
+        if (br) atomicMax(p.nd2max_bits + 3, br);
+    }
 }
 void launch_row_stats(const RowStatsParams& p, hipStream_t s) {
     uint32_t n = p.row_end - p.row_begin;
@@ -184,6 +202,25 @@ __global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepParams p) {
         float v = (q < p.nq && i < p.dim) ? src[i] : 0.0f;
         dst[i] = v;
         sQrow[i] = v;
+        if (p.qb) p.qb[(size_t)q * p.ld + i] = __builtin_bit_cast(uint16_t, (__bf16)v);   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    }
+    if (p.qb) {
+        // |q - bf16(q)|: any summation order will do (it is an upper bound, rounded up below)
+        float e2 = 0.0f;
+        for (uint32_t i = threadIdx.x; i < p.ld; i += blockDim.x) {
+            float v = (q < p.nq && i < p.dim) ? src[i] : 0.0f;
+            float e = v - bf16_round(v);
+            e2 += e * e;
+        }
+        for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o);
+        __shared__ float sE[4];
+        if ((threadIdx.x & 63) == 0) sE[threadIdx.x >> 6] = e2;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = (sE[0] + sE[1]) + (sE[2] + sE[3]);
+            t = __builtin_sqrtf(t) * 1.0001f;
+            p.qerr[q] = (t == t) ? t : 0.0f;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -567,7 +604,27 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankParams p) {
             double eps = (double)p.eps_coef;
             double ndmax = sqrt((double)__uint_as_float(*p.nd2max_bits));
             bool ok;
-            if (p.metric == DOT) {
+            if (p.qerr) {
+                // bf16 screening tier.  With e_q = q - bf16(q) (known) and e_d = d - bf16(d):
+                //   dot(q,d) - dot(bf16 q, bf16 d) = e_q.d + bf16(q).e_d ,  |.| <= |e_q||d| + |bf16 q||e_d|   (Cauchy-Schwarz)
+                // plus the f32 accumulation inside the MFMAs (c_acc |q||d|).  |bf16 q| <= 1.004 |q|; 1 % covers the f32
+                // evaluation of the norms.  eps is the f32 tier's coefficient (oracle fold + fma chain).
+                const double eq = (double)p.qerr[q];
+                const double emax = sqrt((double)__uint_as_float(p.nd2max_bits[2]));
+                const double rmax = sqrt((double)__uint_as_float(p.nd2max_bits[3]));
+                const double cacc = (double)p.c_acc;
+                if (p.metric == DOT) {
+                    const double E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
+                    ok = ek < (double)T - E - eps * qn * ndmax;
+                } else if (p.metric == COSINE) {
+                    const double Ec = 1.01 * (eq / qn + 1.004 * rmax) + cacc;
+                    ok = ek < 1.0 + (double)T / qn - Ec - eps;
+                } else {
+                    const double E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
+                    double s = qn + ndmax;
+                    ok = ek * ek < (double)T + qn * qn - 2.0 * E - eps * (s * s + ek * ek);
+                }
+            } else if (p.metric == DOT) {
                 ok = ek < (double)T - eps * qn * ndmax;
             } else if (p.metric == COSINE) {
                 ok = ek < 1.0 + (double)T / qn - eps;
@@ -579,6 +636,10 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankParams p) {
             // asked for while the candidate list was full, cannot be certified either
             if (!ok || sNanKey || real < p.kp) cert = 0;
             if (nout < p.k) cert = 0;
+        } else if (cnt < p.kp && p.thr && p.thr[q] < __uint_as_float(0x7f800000u)) {
+            // fewer candidates than asked for although a finite threshold (met by >= kp sampled rows) was in force:
+            // the filter pass and the sample disagree -- never certify that
+            cert = 0;
         }
         p.cert[q] = cert;
     }
@@ -594,6 +655,46 @@ void launch_rerank(const RerankParams& p, uint32_t nq, hipStream_t s) {
     q.lds_chunk = chunk;
     size_t lds = (size_t)(chunk + 1) * q.lds_row_stride * 4;   // dim <= ~19000 fits with chunk = 1
     hipLaunchKernelGGL(rerank_kernel, dim3(nq), dim3(256), lds, s, q);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Compact re-run of uncertified queries by the next tier: gather their padded rows and norms into a
+// dense block, and scatter the block's results back to the batch positions.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_queries_kernel(const float* qp, const float* qnorm, uint32_t ld,
+                                                             const uint32_t* qidx, uint32_t n, float* qp_out,
+                                                             float* qnorm_out, float* thr_out) {
+    const uint32_t j = blockIdx.x;                     // < n_pad: the padding rows are zero, their threshold -inf
+    const bool real = j < n;
+    const uint32_t q = real ? qidx[j] : 0u;
+    for (uint32_t i = threadIdx.x; i < ld; i += blockDim.x) qp_out[(size_t)j * ld + i] = real ? qp[(size_t)q * ld + i] : 0.0f;
+    if (threadIdx.x == 0) {
+        qnorm_out[j] = real ? qnorm[q] : 0.0f;
+        thr_out[j] = __uint_as_float(0xff800000u);
+    }
+}
+void launch_gather_queries(const float* qp, const float* qnorm, uint32_t ld, const uint32_t* qidx, uint32_t n,
+                           uint32_t n_pad, float* qp_out, float* qnorm_out, float* thr_out, hipStream_t s) {
+    if (!n_pad) return;
+    hipLaunchKernelGGL(gather_queries_kernel, dim3(n_pad), dim3(256), 0, s, qp, qnorm, ld, qidx, n, qp_out, qnorm_out,
+                       thr_out);
+}
+__global__ __launch_bounds__(128) void scatter_results_kernel(const uint64_t* ids, const float* dists,
+                                                              const uint32_t* counts, const uint32_t* qidx, uint32_t k,
+                                                              uint64_t* out_ids, float* out_dists, uint32_t* out_counts) {
+    const uint32_t j = blockIdx.x, q = qidx[j];
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        out_ids[(size_t)q * k + i] = ids[(size_t)j * k + i];
+        out_dists[(size_t)q * k + i] = dists[(size_t)j * k + i];
+    }
+    if (threadIdx.x == 0) out_counts[q] = counts[j];
+}
+void launch_scatter_results(const uint64_t* ids, const float* dists, const uint32_t* counts, const uint32_t* qidx,
+                            uint32_t n, uint32_t k, uint64_t* out_ids, float* out_dists, uint32_t* out_counts,
+                            hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(scatter_results_kernel, dim3(n), dim3(128), 0, s, ids, dists, counts, qidx, k, out_ids, out_dists,
+                       out_counts);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -115,17 +115,23 @@ struct vdb_flat_index {
 
     // device store
     float* d_rows = nullptr; float* d_nd = nullptr; float* d_alpha = nullptr; float* d_beta = nullptr;
-    uint64_t* d_row_ids = nullptr; uint32_t* d_live = nullptr; uint32_t* d_scalars = nullptr;  // [0]=nd2max bits [1]=zero count
+    uint64_t* d_row_ids = nullptr; uint32_t* d_live = nullptr; uint32_t* d_scalars = nullptr;  // [0]=nd2max bits [1]=zero count [2],[3]=max bf16 rounding error of a row (abs^2, rel^2)
     uint32_t cap_rows = 0;
     bool zero_valid = false; uint32_t zero_live = 0;
     DevBuf<uint32_t> d_idrank, d_rank2row; bool rank_valid = false;
 
     // search workspace
-    DevBuf<float> w_qp, w_qnorm, w_thr, w_qin, w_outd;
+    DevBuf<float> w_qp, w_qnorm, w_thr, w_qin, w_outd, w_qerr;
     DevBuf<uint64_t> w_dense, w_samp, w_pool, w_cand, w_exact, w_exsel, w_mask_ids, w_outi;
     DevBuf<uint32_t> w_cnt, w_rowmask, w_flags, w_outc, w_subcnt;
+    DevBuf<uint16_t> w_qb;                                  // bf16 copy of the padded queries (screening tier)
+    // compact block of the queries the screening tier could not certify (re-run by the f32 tier)
+    DevBuf<float> w2_qp, w2_qnorm, w2_thr, w2_outd;
+    DevBuf<uint64_t> w2_outi;
+    DevBuf<uint32_t> w2_outc, w2_flags, w2_qidx;
     uint32_t* h_flags = nullptr; size_t h_flags_n = 0;
-    uint64_t stats[8] = {0};
+    int screen = 1;                                         // 1: bf16 screening tier first (default), 0: f32 MFMA tier only
+    uint64_t stats[16] = {0};
     bool profile = false; hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     uint32_t n_rows() const { return (uint32_t)row_ids.size(); }
@@ -195,7 +201,7 @@ void reset_rows(Index* ix) {
     ix->n_live = 0; ix->n_uploaded = 0; ix->dim = 0; ix->ld = 0; ix->ids_monotone = true;
     ix->zero_valid = false; ix->rank_valid = false; ix->live_dirty = false;
     free_store(ix);
-    if (ix->d_scalars) (void)hipMemsetAsync(ix->d_scalars, 0, 8, ix->stream);
+    if (ix->d_scalars) (void)hipMemsetAsync(ix->d_scalars, 0, 16, ix->stream);
 }
 
 void kill_row(Index* ix, uint32_t row) {
@@ -350,6 +356,22 @@ float eps_coef(const Index* ix) {
     return (float)c;
 }
 
+// f32 accumulation inside the bf16 MFMAs (products of two bf16 are exact in f32): at most K 2^-22 |q||d|, 5 % margin.
+// The operand-rounding part of the screening tier's error bound is evaluated per query in rerank_kernel from the
+// known |q - bf16(q)| and the per-index maxima of |d - bf16(d)| (row_stats_kernel).
+float c_acc_bf16(const Index* ix) {
+    double c = (double)ix->ld * 2.384185791015625e-07 * 1.05;
+    if (const char* e = getenv("VDB_EPS_SCALE")) c *= atof(e);
+    return (float)c;
+}
+
+// candidates kept per query by the bf16 screening tier (0: k too large for it)
+uint32_t pick_kp_bf16(size_t k) {
+    if (k <= 16) return 64;
+    if (k <= 64) return 128;
+    return 0;
+}
+
 uint32_t pick_kp(size_t k) {
     size_t want = k + std::max<size_t>(6, k / 5);
     if (want <= 32) return 32;
@@ -388,6 +410,179 @@ int exact_one(Index* ix, hipStream_t s, uint32_t q, size_t k, const uint32_t* d_
         vdb::launch_emit(em, s);
     }
     HIP_TRY(hipGetLastError());
+    return VDB_OK;
+}
+
+// ------------------------------------------------------------------ tier: f32 MFMA scores + certified re-rank
+// Runs the f32 pipeline for the nq queries whose padded rows start at qp (stride ld; the block
+// must be readable and zero up to a multiple of 256 rows, thr = -inf in the padding), writing results for query j
+// at out_*[j*k ..] and the certification / pool-overflow flags at d_cert[j] / d_ovf[j].
+int pass_f32(Index* ix, hipStream_t s, const float* qp, const float* qnorm, float* thr, uint32_t nq, size_t k, uint32_t kp,
+             const uint32_t* d_rowmask, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, uint32_t* d_cert,
+             uint32_t* d_ovf, uint32_t* d_status) {
+    int rc;
+    const uint32_t n = ix->n_uploaded, ld = ix->ld;
+    const bool small = n <= SMALL_N;
+    // Threshold sample size S: the fused pass keeps about n*kp/S keys per query, spread over 512 private
+    // sub-pools of 64 slots and gathered into 16384 LDS slots by the select.  S is chosen so that this
+    // expectation stays near 8000 or below (mean sub-pool fill <= 16), and the sample costs <= ~3 % of the
+    // fused pass for k = 10.
+    uint32_t S = n;
+    if (!small) {
+        uint64_t want = std::max<uint64_t>(n / 256u, (uint64_t)n * kp / 8000u);
+        S = (uint32_t)std::min<uint64_t>(65536u, std::max<uint64_t>(2048u, pow2_ceil(want)));
+        if (const char* e = getenv("VDB_SAMPLE")) S = std::min<uint32_t>(n, std::max(64, atoi(e)));
+    }
+    // candidate pools: one private sub-pool per (query, row range, row part, lane half) of the fused kernel
+    const uint32_t capl = 64;
+    // sub-pools in one pass = queries * row ranges * row parts * 2 = 512 * n_cu for every kernel shape
+    const size_t pass_subs = 512u * (size_t)ix->n_cu;
+    if ((rc = ix->w_dense.ensure((size_t)SUPER * S))) return rc;
+    if ((rc = ix->w_cand.ensure((size_t)SUPER * kp))) return rc;
+    if (!small) {
+        if ((rc = ix->w_samp.ensure((size_t)SUPER * kp))) return rc;
+        if ((rc = ix->w_pool.ensure(pass_subs * capl))) return rc;
+        if ((rc = ix->w_subcnt.ensure(pass_subs))) return rc;
+    }
+    uint32_t* d_cnt_a = ix->w_cnt.p;               // sample select counts
+    uint32_t* d_cand_cnt = ix->w_cnt.p + 2 * SUPER;
+    if (!ix->stats[8]) { ix->stats[4] = S; ix->stats[5] = kp; }
+    const float eps = eps_coef(ix);
+
+    for (uint32_t q0 = 0; q0 < nq; q0 += SUPER) {
+        const uint32_t nb = std::min(SUPER, nq - q0);
+        const uint32_t tiles = (nb + 31) / 32;
+        // fused-kernel shape: 32 / 64 / 128 queries per workgroup; 2 workgroups per CU in flight
+        static const bool shape8 = getenv("VDB_FUSED_SHAPE4") == nullptr;   // default: ONE 8-wave workgroup per CU, 256 queries share each fetched row tile (VDB_FUSED_SHAPE4 = two 4-wave workgroups of 128 queries)
+        const int nqt = (shape8 && tiles > 4) ? 8 : tiles > 2 ? 4 : (int)tiles;
+        const uint32_t n_super = (tiles + nqt - 1) / nqt;          // workgroups along the query axis (1 or 2)
+        const float* qp0 = qp + (size_t)q0 * ld;
+
+        vdb::DenseParams dp{ix->d_rows, ld, n, qp0, round_up(nb, 32), ix->d_alpha, ix->d_beta, d_rowmask, S,
+                            ix->w_dense.p, S};
+        vdb::launch_dense_scores(dp, s);
+
+        vdb::SelectParams sp{};
+        sp.keys = ix->w_dense.p; sp.stride = S; sp.counts = nullptr; sp.n_fixed = S; sp.cap = S; sp.kk = kp;
+        sp.out_stride = kp;
+        if (small) {
+            sp.out_keys = ix->w_cand.p; sp.out_cnt = d_cand_cnt; sp.out_thr = nullptr; sp.ovf = nullptr;
+            vdb::launch_select(sp, nb, s);
+        } else {
+            // thresholds: the sample's kp-th score (padding queries were given -inf by query_prep)
+            sp.out_keys = ix->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = thr + q0; sp.ovf = nullptr;
+            vdb::launch_select(sp, nb, s);
+            const uint32_t n_wg = std::min<uint32_t>((nqt == 8 ? 1u : 2u) * (uint32_t)ix->n_cu / n_super, (n + 31) / 32);
+            const uint32_t n_sub = vdb::fused_subpools_per_query(nqt, n_wg);
+            vdb::FusedParams fp{ix->d_rows, ld, n, qp, q0, ix->d_alpha, ix->d_beta, d_rowmask ? d_rowmask : ix->d_live,
+                                thr, ix->w_pool.p - (size_t)q0 * n_sub * capl,
+                                ix->w_subcnt.p - (size_t)q0 * n_sub, capl, n_wg,
+                                getenv("VDB_FUSED_ABLATE") ? (uint32_t)atoi(getenv("VDB_FUSED_ABLATE")) : 0u};
+            const bool prof = ix->profile && !ix->stats[8];       // with the screening tier on, ITS kernel is the one timed
+            if (prof) HIP_TRY(hipEventRecord(ix->ev0, s));
+            static const bool use_dma = getenv("VDB_FUSED_REGSTAGE") == nullptr;   // default: LDS-DMA staging (VDB_FUSED_REGSTAGE=1: register-staged variant, same results)
+            static const bool use_dma3 = getenv("VDB_FUSED_DMA2") == nullptr;   // default: 3-image ring with the barrier in mid-stage (VDB_FUSED_DMA2=1: 2-image variant)
+            if (use_dma && use_dma3 && nqt == 8) vdb::launch_fused_dma3(fp, n_super, s);
+            else if (use_dma && nqt == 8) vdb::launch_fused_dma(fp, n_super, s);
+            else vdb::launch_fused(fp, nqt, n_super, s);
+            if (prof) {
+                // one super-tile per event pair: wait here so the pair can be reused (profiling mode only)
+                HIP_TRY(hipEventRecord(ix->ev1, s));
+                HIP_TRY(hipEventSynchronize(ix->ev1));
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+                ix->stats[7] += (uint64_t)((double)ms * 1e6);
+            }
+            ix->stats[3] += n;
+            vdb::SelectParams mp{};
+            mp.keys = ix->w_pool.p; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
+            mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl;
+            mp.kk = kp; mp.out_keys = ix->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
+            mp.out_thr = nullptr; mp.ovf = d_ovf + q0;
+            vdb::launch_select(mp, nb, s);
+        }
+        vdb::RerankParams rp{};
+        rp.rows = ix->d_rows; rp.ld = ld; rp.dim = ix->dim; rp.n_rows = n;
+        rp.qp = qp0; rp.qnorm = qnorm + q0; rp.nd = ix->d_nd; rp.row_ids = ix->d_row_ids;
+        rp.rowmask = d_rowmask; rp.cand = ix->w_cand.p; rp.cand_stride = kp; rp.cand_cnt = d_cand_cnt; rp.kp = kp;
+        rp.metric = ix->metric; rp.k = (uint32_t)k; rp.eps_coef = eps; rp.nd2max_bits = ix->d_scalars;
+        rp.out_ids = d_out_ids + (size_t)q0 * k; rp.out_dists = d_out_dists + (size_t)q0 * k;
+        rp.out_counts = d_out_counts + q0; rp.out_stride = (uint32_t)k; rp.cert = d_cert + q0; rp.status = d_status;
+        rp.thr = small ? nullptr : thr + q0;
+        vdb::launch_rerank(rp, nb, s);
+    }
+    return VDB_OK;
+}
+
+// ------------------------------------------------------------------ tier: bf16 screening + certified re-rank
+// Same structure, with the scores of the HBM-bound bf16 kernel (kernels_fused_bf16.hip): group minima of a row
+// sample -> per-query threshold -> one pass over all rows keeping the keys under the threshold -> the kp smallest
+// keys -> exact re-rank, certified with the bf16 error bound.  Queries come from ix->w_qp / w_qb / w_qnorm.
+int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, uint32_t kp, const uint32_t* d_rowmask,
+              uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, uint32_t* d_cert, uint32_t* d_ovf,
+              uint32_t* d_status) {
+    int rc;
+    const uint32_t n = ix->n_uploaded, ld = ix->ld;
+    // sample size: the filter pass keeps about n*kp/S keys per query (target ~2000), 64 <= groups <= 16384
+    uint32_t S = (uint32_t)std::min<uint64_t>(65536u, std::max<uint64_t>(4096u, pow2_ceil((uint64_t)n * kp / 2048u)));
+    if (const char* e = getenv("VDB_SAMPLE16")) S = std::max(256, atoi(e));
+    S = std::min(S, n / 256u * 256u);
+    const uint32_t M = vdb::fused_bf16_sample_groups(S);
+    const uint32_t capl = 64;
+    const uint32_t n_wg = std::min<uint32_t>((uint32_t)ix->n_cu, (n + 31) / 32);
+    const uint32_t n_sub = vdb::fused_bf16_subpools_per_query(n_wg);
+    if ((rc = ix->w_dense.ensure((size_t)SUPER * M))) return rc;
+    if ((rc = ix->w_cand.ensure((size_t)SUPER * kp))) return rc;
+    if ((rc = ix->w_samp.ensure((size_t)SUPER * kp))) return rc;
+    if ((rc = ix->w_pool.ensure((size_t)SUPER * n_sub * capl))) return rc;
+    if ((rc = ix->w_subcnt.ensure((size_t)SUPER * n_sub))) return rc;
+    uint32_t* d_cnt_a = ix->w_cnt.p;
+    uint32_t* d_cand_cnt = ix->w_cnt.p + 2 * SUPER;
+    ix->stats[4] = S;
+    const float eps = eps_coef(ix);
+    for (uint32_t q0 = 0; q0 < nq; q0 += SUPER) {
+        const uint32_t nb = std::min(SUPER, nq - q0);
+        vdb::FusedBf16Params fp{};
+        fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w_qb.p + (size_t)q0 * ld;
+        fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
+        fp.thr = ix->w_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
+        fp.n_sample = S; fp.minkeys = ix->w_dense.p; fp.minkey_stride = M;
+        vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);
+
+        vdb::SelectParams sp{};
+        sp.keys = ix->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = kp;
+        sp.out_stride = kp; sp.out_keys = ix->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->w_thr.p + q0; sp.ovf = nullptr;
+        vdb::launch_select(sp, nb, s);
+
+        if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
+        vdb::launch_fused_bf16(fp, s);
+        if (ix->profile) {
+            HIP_TRY(hipEventRecord(ix->ev1, s));
+            HIP_TRY(hipEventSynchronize(ix->ev1));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
+            ix->stats[7] += (uint64_t)((double)ms * 1e6);
+        }
+        ix->stats[3] += n;
+
+        vdb::SelectParams mp{};
+        mp.keys = ix->w_pool.p; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
+        mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl;
+        mp.kk = kp; mp.out_keys = ix->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
+        mp.out_thr = nullptr; mp.ovf = d_ovf + q0;
+        vdb::launch_select(mp, nb, s);
+
+        vdb::RerankParams rp{};
+        rp.rows = ix->d_rows; rp.ld = ld; rp.dim = ix->dim; rp.n_rows = n;
+        rp.qp = ix->w_qp.p + (size_t)q0 * ld; rp.qnorm = ix->w_qnorm.p + q0; rp.nd = ix->d_nd; rp.row_ids = ix->d_row_ids;
+        rp.rowmask = d_rowmask; rp.cand = ix->w_cand.p; rp.cand_stride = kp; rp.cand_cnt = d_cand_cnt; rp.kp = kp;
+        rp.metric = ix->metric; rp.k = (uint32_t)k; rp.eps_coef = eps; rp.nd2max_bits = ix->d_scalars;
+        rp.out_ids = d_out_ids + (size_t)q0 * k; rp.out_dists = d_out_dists + (size_t)q0 * k;
+        rp.out_counts = d_out_counts + q0; rp.out_stride = (uint32_t)k; rp.cert = d_cert + q0; rp.status = d_status;
+        rp.thr = ix->w_thr.p + q0;
+        rp.qerr = ix->w_qerr.p + q0; rp.c_acc = c_acc_bf16(ix);
+        vdb::launch_rerank(rp, nb, s);
+    }
     return VDB_OK;
 }
 
@@ -430,14 +625,12 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
     const uint32_t nq32 = (uint32_t)nq;
     const uint32_t bp_all = round_up(nq32, SUPER);
     const uint32_t kp = pick_kp(k);
-    ix->stats[5] = kp;
 
     // ---- workspace
     if ((rc = ix->w_qp.ensure((size_t)bp_all * ld))) return rc;
     if ((rc = ix->w_qnorm.ensure(bp_all))) return rc;
     if ((rc = ix->w_thr.ensure(bp_all))) return rc;
     if ((rc = ix->w_flags.ensure(4 + 2 * (size_t)nq32))) return rc;
-    if ((rc = ix->w_cnt.ensure(4 * SUPER + 16))) return rc;
     if (ix->h_flags_n < 4 + 2 * (size_t)nq32) {
         if (ix->h_flags) (void)hipHostFree(ix->h_flags);
         ix->h_flags = nullptr;
@@ -461,7 +654,14 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
 
     // ---- queries: zero-padded copy + exact-order norms
     {
-        vdb::QueryPrepParams qp{d_q, (uint32_t)dim, nq32, ix->w_qp.p, ld, bp_all, ix->w_qnorm.p, ix->w_thr.p, ix->metric, d_status};
+        uint16_t* qb = nullptr;
+        if (ix->screen && n > SMALL_N && pick_kp_bf16(k)) {
+            if ((rc = ix->w_qb.ensure((size_t)bp_all * ld))) return rc;
+            if ((rc = ix->w_qerr.ensure(bp_all))) return rc;
+            qb = ix->w_qb.p;
+        }
+        vdb::QueryPrepParams qp{d_q, (uint32_t)dim, nq32, ix->w_qp.p, ld, bp_all, ix->w_qnorm.p, ix->w_thr.p, ix->metric, d_status, qb,
+                                ix->w_qerr.p};
         vdb::launch_query_prep(qp, s);
     }
 
@@ -483,113 +683,82 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
         return VDB_OK;
     }
 
-    // ---- sizes of the threshold sample and the candidate pools
+    // ---- tiers.  Large indexes: the bf16 screening tier first (HBM-bound pass), the queries it cannot certify
+    // are re-run as a compact block by the f32 MFMA tier; whatever that cannot certify goes to the exact scan.
     const bool small = n <= SMALL_N;
-    // Threshold sample size S: the fused pass keeps about n*kp/S keys per query, spread over 512 private
-    // sub-pools of 64 slots and gathered into 16384 LDS slots by the select.  S is chosen so that this
-    // expectation stays near 8000 or below (mean sub-pool fill <= 16), and the sample costs <= ~3 % of the
-    // fused pass for k = 10.
-    uint32_t S = n;
-    if (!small) {
-        uint64_t want = std::max<uint64_t>(n / 256u, (uint64_t)n * kp / 8000u);
-        S = (uint32_t)std::min<uint64_t>(65536u, std::max<uint64_t>(2048u, pow2_ceil(want)));
-        if (const char* e = getenv("VDB_SAMPLE")) S = std::min<uint32_t>(n, std::max(64, atoi(e)));
-    }
-    // candidate pools: one private sub-pool per (query, row range, row part, lane half) of the fused kernel
-    const uint32_t capl = 64;
-    // sub-pools in one pass = queries * row ranges * row parts * 2 = 512 * n_cu for every kernel shape
-    const size_t pass_subs = 512u * (size_t)ix->n_cu;
-    if ((rc = ix->w_dense.ensure((size_t)SUPER * S))) return rc;
-    if ((rc = ix->w_cand.ensure((size_t)SUPER * kp))) return rc;
-    if (!small) {
-        if ((rc = ix->w_samp.ensure((size_t)SUPER * kp))) return rc;
-        if ((rc = ix->w_pool.ensure(pass_subs * capl))) return rc;
-        if ((rc = ix->w_subcnt.ensure(pass_subs))) return rc;
-    }
-    uint32_t* d_cnt_a = ix->w_cnt.p;               // sample select counts
-    uint32_t* d_cand_cnt = ix->w_cnt.p + 2 * SUPER;
-    ix->stats[4] = S;
-    const float eps = eps_coef(ix);
-
-    for (uint32_t q0 = 0; q0 < nq32; q0 += SUPER) {
-        const uint32_t nb = std::min(SUPER, nq32 - q0);
-        const uint32_t tiles = (nb + 31) / 32;
-        // fused-kernel shape: 32 / 64 / 128 queries per workgroup; 2 workgroups per CU in flight
-        static const bool shape8 = getenv("VDB_FUSED_SHAPE4") == nullptr;   // default: ONE 8-wave workgroup per CU, 256 queries share each fetched row tile (VDB_FUSED_SHAPE4 = two 4-wave workgroups of 128 queries)
-        const int nqt = (shape8 && tiles > 4) ? 8 : tiles > 2 ? 4 : (int)tiles;
-        const uint32_t n_super = (tiles + nqt - 1) / nqt;          // workgroups along the query axis (1 or 2)
-        const float* qp0 = ix->w_qp.p + (size_t)q0 * ld;
-
-        vdb::DenseParams dp{ix->d_rows, ld, n, qp0, round_up(nb, 32), ix->d_alpha, ix->d_beta, d_rowmask, S,
-                            ix->w_dense.p, S};
-        vdb::launch_dense_scores(dp, s);
-
-        vdb::SelectParams sp{};
-        sp.keys = ix->w_dense.p; sp.stride = S; sp.counts = nullptr; sp.n_fixed = S; sp.cap = S; sp.kk = kp;
-        sp.out_stride = kp;
-        if (small) {
-            sp.out_keys = ix->w_cand.p; sp.out_cnt = d_cand_cnt; sp.out_thr = nullptr; sp.ovf = nullptr;
-            vdb::launch_select(sp, nb, s);
-        } else {
-            // thresholds: the sample's kp-th score (padding queries were given -inf by query_prep)
-            sp.out_keys = ix->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->w_thr.p + q0; sp.ovf = nullptr;
-            vdb::launch_select(sp, nb, s);
-            const uint32_t n_wg = std::min<uint32_t>((nqt == 8 ? 1u : 2u) * (uint32_t)ix->n_cu / n_super, (n + 31) / 32);
-            const uint32_t n_sub = vdb::fused_subpools_per_query(nqt, n_wg);
-            vdb::FusedParams fp{ix->d_rows, ld, n, ix->w_qp.p, q0, ix->d_alpha, ix->d_beta, d_rowmask ? d_rowmask : ix->d_live,
-                                ix->w_thr.p, ix->w_pool.p - (size_t)q0 * n_sub * capl,
-                                ix->w_subcnt.p - (size_t)q0 * n_sub, capl, n_wg,
-                                getenv("VDB_FUSED_ABLATE") ? (uint32_t)atoi(getenv("VDB_FUSED_ABLATE")) : 0u};
-            if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
-            static const bool use_dma = getenv("VDB_FUSED_REGSTAGE") == nullptr;   // default: LDS-DMA staging (VDB_FUSED_REGSTAGE=1: register-staged variant, same results)
-            static const bool use_dma3 = getenv("VDB_FUSED_DMA2") == nullptr;   // default: 3-image ring with the barrier in mid-stage (VDB_FUSED_DMA2=1: 2-image variant)
-            if (use_dma && use_dma3 && nqt == 8) vdb::launch_fused_dma3(fp, n_super, s);
-            else if (use_dma && nqt == 8) vdb::launch_fused_dma(fp, n_super, s);
-            else vdb::launch_fused(fp, nqt, n_super, s);
-            if (ix->profile) {
-                // one super-tile per event pair: wait here so the pair can be reused (profiling mode only)
-                HIP_TRY(hipEventRecord(ix->ev1, s));
-                HIP_TRY(hipEventSynchronize(ix->ev1));
-                float ms = 0.f;
-                HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
-                ix->stats[7] += (uint64_t)((double)ms * 1e6);
-            }
-            ix->stats[3] += n;
-            vdb::SelectParams mp{};
-            mp.keys = ix->w_pool.p; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
-            mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl;
-            mp.kk = kp; mp.out_keys = ix->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
-            mp.out_thr = nullptr; mp.ovf = d_ovf + q0;
-            vdb::launch_select(mp, nb, s);
-        }
-        vdb::RerankParams rp{};
-        rp.rows = ix->d_rows; rp.ld = ld; rp.dim = ix->dim; rp.n_rows = n;
-        rp.qp = qp0; rp.qnorm = ix->w_qnorm.p + q0; rp.nd = ix->d_nd; rp.row_ids = ix->d_row_ids;
-        rp.rowmask = d_rowmask; rp.cand = ix->w_cand.p; rp.cand_stride = kp; rp.cand_cnt = d_cand_cnt; rp.kp = kp;
-        rp.metric = ix->metric; rp.k = (uint32_t)k; rp.eps_coef = eps; rp.nd2max_bits = ix->d_scalars;
-        rp.out_ids = d_out_ids + (size_t)q0 * k; rp.out_dists = d_out_dists + (size_t)q0 * k;
-        rp.out_counts = d_out_counts + q0; rp.out_stride = (uint32_t)k; rp.cert = d_cert + q0; rp.status = d_status;
-        vdb::launch_rerank(rp, nb, s);
+    const uint32_t kp16 = (ix->screen && !small) ? pick_kp_bf16(k) : 0;
+    if ((rc = ix->w_cnt.ensure(4 * SUPER + 16))) return rc;
+    if (kp16) {
+        ix->stats[8] = 1;
+        ix->stats[5] = kp16;
+        if ((rc = pass_bf16(ix, s, nq32, k, kp16, d_rowmask, d_out_ids, d_out_dists, d_out_counts, d_cert, d_ovf, d_status)))
+            return rc;
+    } else {
+        if ((rc = pass_f32(ix, s, ix->w_qp.p, ix->w_qnorm.p, ix->w_thr.p, nq32, k, kp, d_rowmask, d_out_ids, d_out_dists,
+                           d_out_counts, d_cert, d_ovf, d_status)))
+            return rc;
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, (4 + 2 * (size_t)nq32) * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    const uint32_t status = ix->h_flags[0];
+    uint32_t status = ix->h_flags[0];
     if (status & vdb::ST_ZERO_QUERY)
         return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
-    // ---- exact fallback for the queries the MFMA path could not certify.  Up to 8 of them share one pass
-    // over the rows; a row survives for a query only if its exact distance is <= the k-th exact distance
-    // the re-rank already found (a valid upper bound), so each query is left with a handful of keys.
-    uint32_t n_fallback = 0;
     const bool force_exact = getenv("VDB_FORCE_EXACT") != nullptr;
     std::vector<uint32_t> todo;
     for (uint32_t q = 0; q < nq32; ++q) {
         bool cert = ix->h_flags[4 + q] != 0, ovf = ix->h_flags[4 + nq32 + q] != 0;
         if (ovf) ++ix->stats[2];
         if (!cert) ++ix->stats[6];
-        if (cert && !ovf && !force_exact) continue;
+        if (cert && !ovf && !force_exact && !(kp16 && getenv("VDB_FORCE_TIER1"))) continue;
         todo.push_back(q);
     }
+    if (kp16 && !todo.empty()) {
+        // ---- second tier: the uncertified queries as one compact block through the f32 MFMA pipeline
+        const uint32_t nf = (uint32_t)todo.size(), nfp = round_up(nf, SUPER);
+        ix->stats[9] = nf;
+        if ((rc = ix->w2_qp.ensure((size_t)nfp * ld))) return rc;
+        if ((rc = ix->w2_qnorm.ensure(nfp))) return rc;
+        if ((rc = ix->w2_thr.ensure(nfp))) return rc;
+        if ((rc = ix->w2_outi.ensure((size_t)nf * k))) return rc;
+        if ((rc = ix->w2_outd.ensure((size_t)nf * k))) return rc;
+        if ((rc = ix->w2_outc.ensure(nf))) return rc;
+        if ((rc = ix->w2_flags.ensure(2 * (size_t)nf))) return rc;
+        if ((rc = ix->w2_qidx.ensure(nf))) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->w2_qidx.p, todo.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(ix->w2_flags.p, 0, 2 * (size_t)nf * 4, s));
+        vdb::launch_gather_queries(ix->w_qp.p, ix->w_qnorm.p, ld, ix->w2_qidx.p, nf, nfp, ix->w2_qp.p, ix->w2_qnorm.p,
+                                   ix->w2_thr.p, s);
+        if (kp == 0) {
+            // k too large for the f32 tier as well: straight to the exact scan (flags stay 0 = uncertified)
+        } else {
+            if ((rc = pass_f32(ix, s, ix->w2_qp.p, ix->w2_qnorm.p, ix->w2_thr.p, nf, k, kp, d_rowmask, ix->w2_outi.p,
+                               ix->w2_outd.p, ix->w2_outc.p, ix->w2_flags.p, ix->w2_flags.p + nf, d_status)))
+                return rc;
+            vdb::launch_scatter_results(ix->w2_outi.p, ix->w2_outd.p, ix->w2_outc.p, ix->w2_qidx.p, nf, (uint32_t)k,
+                                        d_out_ids, d_out_dists, d_out_counts, s);
+        }
+        HIP_TRY(hipGetLastError());
+        std::vector<uint32_t> f2(2 * (size_t)nf + 4);
+        HIP_TRY(hipMemcpyAsync(f2.data(), ix->w2_flags.p, 2 * (size_t)nf * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(f2.data() + 2 * (size_t)nf, ix->w_flags.p, 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        status |= f2[2 * (size_t)nf];
+        if (status & vdb::ST_ZERO_QUERY)
+            return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
+        std::vector<uint32_t> todo2;
+        for (uint32_t j = 0; j < nf; ++j) {
+            bool cert = f2[j] != 0, ovf = f2[nf + j] != 0;
+            if (ovf) ++ix->stats[2];
+            if (cert && !ovf && !force_exact) continue;
+            todo2.push_back(todo[j]);
+        }
+        todo.swap(todo2);
+    }
+    // ---- exact fallback for the queries the MFMA tiers could not certify.  Up to 8 of them share one pass
+    // over the rows; a row survives for a query only if its exact distance is <= the k-th exact distance
+    // the re-rank already found (a valid upper bound), so each query is left with a handful of keys.
+    uint32_t n_fallback = 0;
     n_fallback = (uint32_t)todo.size();
     if (!todo.empty()) {
         const uint32_t cap = 32768;
@@ -679,6 +848,7 @@ int vdb_flat_create(int metric, int device, vdb_flat_index** out) {
     ix->metric = metric;
     ix->device = device;
     ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("VDB_SCREEN")) ix->screen = strcmp(e, "f32") != 0 && strcmp(e, "0") != 0;
     if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ix;
         return fail(VDB_ERR_DEVICE, "hipStreamCreate failed");
@@ -702,6 +872,8 @@ void vdb_flat_destroy(vdb_flat_index* ix) {
     ix->w_qp.release(); ix->w_qnorm.release(); ix->w_thr.release(); ix->w_qin.release(); ix->w_outd.release();
     ix->w_dense.release(); ix->w_samp.release(); ix->w_pool.release(); ix->w_cand.release(); ix->w_exact.release();
     ix->w_exsel.release(); ix->w_mask_ids.release(); ix->w_outi.release();
+    ix->w_qb.release(); ix->w_qerr.release(); ix->w2_qp.release(); ix->w2_qnorm.release(); ix->w2_thr.release(); ix->w2_outd.release();
+    ix->w2_outi.release(); ix->w2_outc.release(); ix->w2_flags.release(); ix->w2_qidx.release();
     ix->w_cnt.release(); ix->w_subcnt.release(); ix->w_rowmask.release(); ix->w_flags.release(); ix->w_outc.release();
     if (ix->h_flags) (void)hipHostFree(ix->h_flags);
     if (ix->ev0) { (void)hipEventDestroy(ix->ev0); (void)hipEventDestroy(ix->ev1); }
@@ -1006,7 +1178,7 @@ int vdb_flat_distances_batch(vdb_flat_index* ix, const float* queries, size_t nq
     HIP_TRY(hipMemcpyAsync(ix->w_rowmask.p, prow.data(), total * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ix->w_rowmask.p + total, pq.data(), total * 4, hipMemcpyHostToDevice, s));
     vdb::QueryPrepParams qp{ix->w_qin.p, (uint32_t)dim, nq32, ix->w_qp.p, ld, bp, ix->w_qnorm.p, ix->w_thr.p, vdb::EUCLID,
-                            ix->w_flags.p};   // metric EUCLID here: zero norms are judged per PAIR below
+                            ix->w_flags.p, nullptr, nullptr};   // metric EUCLID here: zero norms are judged per PAIR below
     vdb::launch_query_prep(qp, s);
     vdb::PairDistParams pp{ix->d_rows, ld, (uint32_t)dim, ix->w_qp.p, ix->w_qnorm.p, ix->d_nd, ix->w_rowmask.p + total,
                            ix->w_rowmask.p, (uint32_t)total, ix->metric, ix->w_outd.p, ix->w_flags.p};
@@ -1051,7 +1223,20 @@ int vdb_flat_set_profile(vdb_flat_index* ix, int on) {
 
 int vdb_flat_last_stats(const vdb_flat_index* ix, uint64_t out[8]) {
     if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
-    memcpy(out, ix->stats, sizeof(ix->stats));
+    memcpy(out, ix->stats, 8 * sizeof(uint64_t));
+    return VDB_OK;
+}
+
+int vdb_flat_last_stats_ex(const vdb_flat_index* ix, uint64_t* out, size_t n) {
+    if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    for (size_t i = 0; i < n; ++i) out[i] = i < 16 ? ix->stats[i] : 0;
+    return VDB_OK;
+}
+
+int vdb_flat_set_screen(vdb_flat_index* ix, int mode) {
+    if (!ix || mode < 0 || mode > 1) return fail(VDB_ERR_INVALID_ARGUMENT, "mode must be 0 (f32 MFMA tier only) or 1 (bf16 screening tier first)");
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->screen = mode;
     return VDB_OK;
 }
 

@@ -236,11 +236,17 @@ class GpuFlatIndex(Index):
         return [out[int(offsets[b]):int(offsets[b + 1])] for b in range(nq)]
 
     def last_stats(self):
-        out = (ctypes.c_uint64 * 8)()
-        self._L.vdb_flat_last_stats(self._h, out)
+        out = (ctypes.c_uint64 * 10)()
+        self._L.vdb_flat_last_stats_ex(self._h, out, 10)
         keys = ["mfma_queries", "exact_queries", "pool_overflows", "rows_scanned", "sample_rows", "kprime",
-                "uncertified", "fused_kernel_ns"]
+                "uncertified", "fused_kernel_ns", "bf16_screen", "f32_tier_queries"]
         return dict(zip(keys, [int(v) for v in out]))
+
+    def set_screen(self, mode):
+        """1 (default): bf16 screening tier first; 0: f32 MFMA tier only.  Results are identical."""
+        rc = self._L.vdb_flat_set_screen(self._h, int(mode))
+        if rc:
+            _raise(rc)
 
     def set_profile(self, on=True):
         rc = self._L.vdb_flat_set_profile(self._h, int(bool(on)))
