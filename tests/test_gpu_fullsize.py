@@ -26,22 +26,27 @@ def big():
     return dict(vdb=vdb, rows=rows, queries=queries, local=gpu_local_search, merge=merge_topk_hip)
 
 
-def build(vdb, metric, rows, first_id=0):
+def build(vdb, metric, rows, first_id=0, screen=1):
     ix = vdb.GpuFlatIndex(vdb.DistanceMetric(metric), keep_host_copy=False)
+    ix.set_screen(screen)
     ix.add_bulk_device(rows.data_ptr(), rows.shape[0], rows.shape[1], first_id=first_id)
     ix.flush()
     return ix
 
 
+@pytest.mark.parametrize("screen", [1, 0], ids=["bf16-screen", "f32-tier"])
 @pytest.mark.parametrize("metric", [0, 1, 2])
-def test_full_size_properties(big, metric):
+def test_full_size_properties(big, metric, screen):
     vdb, rows, queries = big["vdb"], big["rows"], big["queries"]
-    ix = build(vdb, metric, rows)
+    ix = build(vdb, metric, rows, screen=screen)
     ids, dists, counts = big["local"](ix)(queries, K)
     torch.cuda.synchronize()
     st = ix.last_stats()
-    assert st["rows_scanned"] == N and st["pool_overflows"] == 0, st
-    assert st["exact_queries"] == 0, st                                     # every query certified on the MFMA path
+    assert st["bf16_screen"] == screen, st
+    assert st["rows_scanned"] >= N and st["pool_overflows"] == 0, st
+    assert st["exact_queries"] == 0, st                                     # every query certified on an MFMA tier
+    if screen:
+        assert st["f32_tier_queries"] <= 8, st                               # (nearly) every query certified by the screening tier
     assert torch.all(counts == K)
     assert torch.all(dists[:, 1:] >= dists[:, :-1])                          # ascending
     assert torch.all((ids >= 0) & (ids < N))
@@ -56,8 +61,8 @@ def test_full_size_properties(big, metric):
     assert torch.equal(ids, ids2) and torch.equal(dists, dists2)
     # two half-size shards merged == the whole index (linearity of the top-k merge)
     half = N // 2
-    a = build(vdb, metric, rows[:half])
-    b = build(vdb, metric, rows[half:], first_id=half)
+    a = build(vdb, metric, rows[:half], screen=screen)
+    b = build(vdb, metric, rows[half:], first_id=half, screen=screen)
     pa, pb = big["local"](a)(queries, K), big["local"](b)(queries, K)
     mi, md, mc = big["merge"](torch.stack([pa[0], pb[0]]), torch.stack([pa[1], pb[1]]),
                               torch.stack([pa[2], pb[2]]), K)
@@ -94,15 +99,17 @@ def test_full_size_prefilter_and_k30(big):
         assert list(gi[b][:len(post)]) == post
 
 
-def test_full_size_k100_stays_on_the_mfma_path(big):
-    """Config-3 style k = 100 (kp = 128): the sample must be sized so that no pool overflows and every
-    query is certified (a too-small sample once sent 1019 of 1024 queries to the exact fallback)."""
+@pytest.mark.parametrize("screen", [1, 0], ids=["bf16-screen", "f32-tier"])
+def test_full_size_k100_stays_on_the_mfma_path(big, screen):
+    """Config-3 style k = 100 (f32 tier: kp = 128; screening tier: up to 256 candidates): the sample must be sized
+    so that no pool overflows and every query is certified by an MFMA tier (a too-small sample once sent 1019 of
+    1024 queries to the exact fallback)."""
     vdb, rows, queries = big["vdb"], big["rows"], big["queries"]
-    ix = build(vdb, 2, rows)
+    ix = build(vdb, 2, rows, screen=screen)
     q_h = queries[:64].cpu().numpy()
     gi, gd, gc = ix.search_batch_arrays(q_h, 100)
     st = ix.last_stats()
-    assert st["kprime"] == 128 and st["exact_queries"] == 0 and st["pool_overflows"] == 0, st
+    assert st["kprime"] == (256 if screen else 128) and st["exact_queries"] == 0 and st["pool_overflows"] == 0, st
     assert np.all(gc == 100)
     rows_h = rows.cpu().numpy()
     for b in (3, 40):

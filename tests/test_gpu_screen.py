@@ -1,0 +1,213 @@
+"""The bf16 screening tier (kernels_fused_bf16.hip) against the CPU oracle and against the f32 MFMA tier.
+
+The tier only RANKS rows on the bf16 matrix cores; what it returns are the reference's exact f32 distances
+(distance.rs:37-73) of certified candidates, so everything here is compared with tolerance 0: ids, order,
+counts and the bit patterns of the distances."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import load_package
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vdb():
+    v = load_package()
+    v.build()
+    return v
+
+
+def make_index(vdb, metric, rows, ids=None):
+    ix = vdb.GpuFlatIndex(vdb.DistanceMetric(metric), keep_host_copy=False)
+    ix.add_bulk(rows, ids=ids)
+    return ix
+
+
+def same(a, b):
+    return all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(a, b))
+
+
+def both_tiers(ix, q, k, **kw):
+    """(results with the screening tier, its stats, results with the f32 tier only)"""
+    ix.set_screen(1)
+    a = ix.search_batch_arrays(q, k, **kw)
+    st = ix.last_stats()
+    ix.set_screen(0)
+    b = ix.search_batch_arrays(q, k, **kw)
+    st0 = ix.last_stats()
+    ix.set_screen(1)
+    assert st0["bf16_screen"] == 0
+    return a, st, b
+
+
+def check_oracle(metric, rows, q, k, res, qsel, ids=None, live=None):
+    gi, gd, gc = res
+    for b in qsel:
+        oi, od = oracle.flat_search(metric, rows, q[b], k, ids=ids, live=live)
+        assert gc[b] == len(oi), (b, gc[b], len(oi))
+        assert np.array_equal(gi[b, :gc[b]], oi), (b, gi[b, :gc[b]], oi)
+        assert np.array_equal(gd[b, :gc[b]].view(np.uint32), od.view(np.uint32)), (b, gd[b, :gc[b]], od)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("n,d,nq,k,dist", [
+    (65536, 32, 40, 10, "gauss"),        # smallest index the tier takes; one K stage per tile
+    (65537, 64, 256, 1, "uniform"),      # two K stages; k = 1
+    (100001, 100, 33, 10, "uniform"),    # dimension padded 100 -> 128, ragged last tile
+    (131072, 768, 256, 10, "uniform"),   # the headline dimension
+    (90000, 1536, 70, 16, "gauss"),      # ada-002 dimension
+    (200000, 48, 300, 50, "gauss"),      # two passes (256 + 44 queries), k = 50
+    (150000, 96, 17, 112, "uniform"),    # largest k the tier serves
+])
+def test_screen_tier_vs_oracle_and_f32_tier(vdb, metric, n, d, nq, k, dist):
+    rng = np.random.default_rng(n + 3 * d + nq + metric)
+    if dist == "uniform":
+        rows = rng.random((n, d), dtype=np.float32)
+        q = rng.random((nq, d), dtype=np.float32)
+    else:
+        rows = rng.standard_normal((n, d)).astype(np.float32)
+        q = rng.standard_normal((nq, d)).astype(np.float32)
+    ix = make_index(vdb, metric, rows)
+    a, st, b = both_tiers(ix, q, k)
+    assert st["bf16_screen"] == 1 and st["kprime"] == 256 and st["rows_scanned"] >= n, st
+    assert st["pool_overflows"] == 0, st
+    assert same(a, b)
+    check_oracle(metric, rows, q, k, a, sorted({0, nq // 2, nq - 1}))
+
+
+def test_screen_tier_not_used_below_its_minimum_or_above_its_k(vdb):
+    rng = np.random.default_rng(3)
+    rows = rng.random((65535, 16), dtype=np.float32)
+    q = rng.random((4, 16), dtype=np.float32)
+    ix = make_index(vdb, 0, rows)
+    ix.search_batch_arrays(q, 10)
+    assert ix.last_stats()["bf16_screen"] == 0
+    rows = rng.random((70000, 16), dtype=np.float32)
+    ix = make_index(vdb, 0, rows)
+    r = ix.search_batch_arrays(q, 113)                                   # k > 112: the f32 tier (kp = 0 -> exact scan)
+    assert ix.last_stats()["bf16_screen"] == 0
+    check_oracle(0, rows, q, 113, r, [0, 3])
+    ix.search_batch_arrays(q, 112)
+    assert ix.last_stats()["bf16_screen"] == 1
+
+
+def test_uncertified_queries_go_through_the_f32_tier(vdb):
+    """VDB_FORCE_TIER1 sends every query of the screening tier to the compact f32 re-run: same results."""
+    rng = np.random.default_rng(21)
+    rows = rng.standard_normal((80000, 72)).astype(np.float32)
+    q = rng.standard_normal((37, 72)).astype(np.float32)
+    for metric in (0, 1, 2):
+        ix = make_index(vdb, metric, rows)
+        a = ix.search_batch_arrays(q, 10)
+        assert ix.last_stats()["f32_tier_queries"] == 0
+        os.environ["VDB_FORCE_TIER1"] = "1"
+        try:
+            b = ix.search_batch_arrays(q, 10)
+            st = ix.last_stats()
+        finally:
+            del os.environ["VDB_FORCE_TIER1"]
+        assert st["bf16_screen"] == 1 and st["f32_tier_queries"] == 37, st
+        assert same(a, b)
+        check_oracle(metric, rows, q, 10, b, [0, 36])
+
+
+def test_duplicates_and_near_ties_fall_through_the_tiers(vdb):
+    """Every row 160 times: the k-th and (k+1)-th distances tie exactly, nothing can be certified by a score
+    bound, and the answer must still be the oracle's (distance, then id)."""
+    rng = np.random.default_rng(22)
+    base = rng.random((500, 40), dtype=np.float32)
+    rows = np.concatenate([base] * 160, 0)                                # 80000 rows
+    ids = rng.permutation(rows.shape[0]).astype(np.uint64)
+    q = base[:5] + 0.0
+    for metric in (0, 1, 2):
+        ix = make_index(vdb, metric, rows, ids=ids)
+        a, st, b = both_tiers(ix, q, 10)
+        assert st["bf16_screen"] == 1
+        assert same(a, b)
+        check_oracle(metric, rows, q, 10, a, range(5), ids=ids)
+
+
+def test_near_duplicates_within_bf16_resolution(vdb):
+    """Rows that differ by less than bf16 can resolve (relative 1e-4): the screening scores cannot order them,
+    the exact re-rank must."""
+    rng = np.random.default_rng(23)
+    n, d = 70000, 64
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    centre = rng.standard_normal(d).astype(np.float32)
+    rows[1000:1300] = centre + 1e-4 * rng.standard_normal((300, d)).astype(np.float32)
+    q = np.stack([centre, centre + 1e-5, rows[1100]]).astype(np.float32)
+    for metric in (0, 1, 2):
+        ix = make_index(vdb, metric, rows)
+        a, st, b = both_tiers(ix, q, 10)
+        assert same(a, b)
+        check_oracle(metric, rows, q, 10, a, range(3))
+
+
+def test_clustered_row_order_overflows_pools_and_still_matches(vdb):
+    """All near neighbours sit in ONE row range (one workgroup's private pools overflow): the overflow flag must
+    route those queries to the next tiers."""
+    rng = np.random.default_rng(24)
+    n, d = 100000, 32
+    rows = rng.standard_normal((n, d)).astype(np.float32) * 10.0
+    rows[5000:5300] = 0.01 * rng.standard_normal((300, d)).astype(np.float32) + 1.0   # a tight cluster of 300 rows
+    q = (np.ones((3, d)) + 0.001 * rng.standard_normal((3, d))).astype(np.float32)
+    ix = make_index(vdb, 0, rows)
+    a, st, b = both_tiers(ix, q, 10)
+    assert same(a, b)
+    check_oracle(0, rows, q, 10, a, range(3))
+
+
+def test_tombstones_overwrites_and_prefilter_under_the_screen_tier(vdb):
+    rng = np.random.default_rng(25)
+    n, d = 90000, 24
+    rows = rng.random((n, d), dtype=np.float32)
+    q = rng.random((20, d), dtype=np.float32)
+    ix = make_index(vdb, 1, rows)
+    live = np.ones(n, dtype=np.uint8)
+    for i in range(0, n, 7):
+        ix.remove(i)
+        live[i] = 0
+    a, st, b = both_tiers(ix, q, 10)
+    assert st["bf16_screen"] == 1
+    assert same(a, b)
+    check_oracle(1, rows, q, 10, a, [0, 19], live=live)
+    # pre-filter: ids with id % 5 == 0 only (device bitmask), on top of the tombstones
+    keep = (np.arange(n) % 5 == 0)
+    mask = np.zeros((n + 63) // 64, dtype=np.uint64)
+    idx = np.nonzero(keep)[0]
+    np.bitwise_or.at(mask, idx >> 6, np.uint64(1) << (idx & 63).astype(np.uint64))
+    ix.set_screen(1)
+    r = ix.search_batch_arrays(q, 10, id_mask=mask, mask_bits=n)
+    assert ix.last_stats()["bf16_screen"] == 1
+    check_oracle(1, rows, q, 10, r, [0, 7, 19], live=(live & keep.astype(np.uint8)))
+    # a very selective filter: fewer eligible rows than the threshold rank -> every eligible row is a candidate
+    keep2 = (np.arange(n) % 3001 == 1)
+    mask2 = np.zeros_like(mask)
+    idx = np.nonzero(keep2)[0]
+    np.bitwise_or.at(mask2, idx >> 6, np.uint64(1) << (idx & 63).astype(np.uint64))
+    r = ix.search_batch_arrays(q, 10, id_mask=mask2, mask_bits=n)
+    check_oracle(1, rows, q, 10, r, [0, 19], live=(live & keep2.astype(np.uint8)))
+
+
+def test_error_semantics_under_the_screen_tier(vdb):
+    V = vdb.Vector
+    rng = np.random.default_rng(26)
+    rows = rng.random((70000, 8), dtype=np.float32)
+    ix = make_index(vdb, 1, rows)
+    with pytest.raises(vdb.InvalidVector):                                # zero-norm query under Cosine (distance.rs:51-55)
+        ix.search(V([0.0] * 8), 3)
+    with pytest.raises(vdb.DimensionMismatch):
+        ix.search(V([1.0] * 7), 3)
+    ix.add(10**6, V([0.0] * 8))                                           # ONE zero-norm row fails every search (flat_index.rs:57-60)
+    with pytest.raises(vdb.InvalidVector):
+        ix.search(V([1.0] * 8), 3)
+    ix.remove(10**6)
+    assert len(ix.search(V([1.0] * 8), 3)) == 3
+    e = make_index(vdb, 0, rows)
+    e.add(10**6, V([float("nan")] + [1.0] * 7))                           # NaN distance: the reference panics (flat_index.rs:62)
+    with pytest.raises(vdb.VectorDbError):
+        e.search(V([1.0] * 8), 3)

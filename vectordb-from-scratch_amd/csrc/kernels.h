@@ -156,8 +156,9 @@ struct FusedBf16Params {
     const float* thr;                                  // [256]
     uint64_t* pool; uint32_t* pool_cnt; uint32_t capl;
     uint32_t n_wg;                                     // row ranges = grid.x
-    // sample mode: sample j -> row j*n_rows/n_sample; per query and group of 64 sample rows the smallest key
-    uint32_t n_sample; uint64_t* minkeys; uint32_t minkey_stride;   // minkeys[q*minkey_stride + group]
+    // sample mode: n_sample = 2^sample_shift <= n_rows, sample j -> row (j*n_rows) >> sample_shift; per query and
+    // group of 64 sample rows the smallest key
+    uint32_t n_sample, sample_shift; uint64_t* minkeys; uint32_t minkey_stride;   // minkeys[q*minkey_stride + group]
 };
 void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s);
 void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s);
@@ -179,7 +180,9 @@ struct RerankParams {
     const float* nd;
     const uint64_t* row_ids;
     const uint32_t* rowmask;                           // may be null
-    const uint64_t* cand; uint32_t cand_stride; const uint32_t* cand_cnt; uint32_t kp;
+    const uint64_t* cand; uint32_t cand_stride; const uint32_t* cand_cnt; uint32_t kp;   // kp <= 256 candidates, sorted by score
+    uint32_t kp_first, kp_step;                        // adaptive depth: re-rank kp_first, then kp_step more per round (0: kp at once)
+    uint32_t* depth;                                   // may be null: candidates re-ranked per query (diagnostics)
     int metric;
     uint32_t k;                                        // results wanted per query
     float eps_coef; const uint32_t* nd2max_bits;       // certification bound inputs (max row norm^2, f32 bits)

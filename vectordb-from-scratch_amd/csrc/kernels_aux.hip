@@ -328,6 +328,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
     uint64_t* sOut = sdyn + SEL_LDS_KEYS;         // [SEL_MAX_KK]
     __shared__ uint32_t sHist[256];
     __shared__ uint32_t sDigit, sRemain, sBucket, sOutCnt, sValid, sN;
+    __shared__ unsigned long long sMinMax[2];
 
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const uint64_t* keys = p.keys + (size_t)q * p.stride;
@@ -335,44 +336,39 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
     bool cached;
     const bool has_lo = p.lo_excl != nullptr;
     const uint64_t lo = has_lo ? p.lo_excl[q] : 0ull;
-    if (tid == 0) { sOutCnt = 0; sValid = 0; sN = 0; }
+    if (tid == 0) { sOutCnt = 0; sValid = 0; sN = 0; sMinMax[0] = ~0ull; sMinMax[1] = 0ull; }
     __syncthreads();
     uint32_t myvalid = 0;
     if (p.n_sub) {
-        // gather the query's private sub-pools (written by the fused kernel) into LDS.  Counts are
-        // staged in LDS first; then each wave takes 4 sub-pools per iteration, lane j reads slot j of
-        // each (four independent coalesced 512-byte loads in flight), and survivors are compacted with
-        // one LDS atomic per sub-pool.  capl is 64 (one slot per lane).
+        // gather the query's private sub-pools (written by the fused kernels) into LDS.  The pools are sparse
+        // (a few keys in each of hundreds of sub-pools), so the gather is driven by the counts: one thread per
+        // sub-pool reads its count (coalesced), a wave scan + one LDS atomic per wave allots the destination
+        // range, and the thread copies its keys -- every load address is known after the count, so all of a
+        // thread's loads are in flight together.
         const uint32_t* sc = p.sub_counts + (size_t)q * p.n_sub;
         const uint64_t* base = p.keys + (size_t)q * p.n_sub * p.capl;
         bool over = false;
-        uint32_t* sCnt = reinterpret_cast<uint32_t*>(sOut);      // sOut is not in use yet: room for 4096 counts
-        for (uint32_t i = tid; i < p.n_sub; i += SEL_THREADS) {
-            uint32_t c = sc[i];
+        for (uint32_t i0 = 0; i0 < p.n_sub; i0 += SEL_THREADS) {
+            const uint32_t i = i0 + tid;
+            uint32_t c = i < p.n_sub ? sc[i] : 0u;
             if (c > p.capl) { c = p.capl; over = true; }
-            sCnt[i] = c;
-        }
-        __syncthreads();
-        const uint32_t wv = tid >> 6;
-        for (uint32_t s0 = wv * 4; s0 < p.n_sub; s0 += 4 * (SEL_THREADS / 64)) {
-            uint32_t c[4];
-            uint64_t k[4];
+            uint32_t incl = c;
+            for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o); if ((int)lane >= o) incl += t; }
+            uint32_t wbase = 0;
+            if (lane == 63 && incl) wbase = atomicAdd(&sN, incl);
+            wbase = __shfl(wbase, 63);
+            uint32_t pos = wbase + incl - c;
+            const uint64_t* src = base + (size_t)i * p.capl;
+            for (uint32_t j0 = 0; j0 < c; j0 += 4) {
+                uint64_t k[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                c[u] = (s0 + u < p.n_sub) ? sCnt[s0 + u] : 0u;
-                k[u] = (lane < c[u]) ? raw_to_key(base[(size_t)(s0 + u) * p.capl + lane]) : EMPTY_KEY;
-            }
+                for (int u = 0; u < 4; ++u) k[u] = (j0 + u < c) ? raw_to_key(src[j0 + u]) : EMPTY_KEY;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (c[u] == 0) continue;                      // wave-uniform
-                const bool have = lane < c[u];
-                unsigned long long m = __ballot(have);
-                uint32_t pos = 0;
-                if (lane == 0) pos = atomicAdd(&sN, (uint32_t)__popcll(m));
-                pos = __shfl(pos, 0) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (have) {
-                    if (pos < SEL_LDS_KEYS) { sKeys[pos] = k[u]; myvalid += (k[u] != EMPTY_KEY); }
-                    else over = true;
+                for (int u = 0; u < 4; ++u) {
+                    if (j0 + u < c) {
+                        if (pos + j0 + u < SEL_LDS_KEYS) { sKeys[pos + j0 + u] = k[u]; myvalid += (k[u] != EMPTY_KEY); }
+                        else over = true;
+                    }
                 }
             }
         }
@@ -406,21 +402,47 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
         return;
     }
     // ---- find the kk-th smallest key
+    // Scores of one query are concentrated (same sign and exponent, often the same leading mantissa bits), so the
+    // leading bytes all keys share are found first (one min / max reduction over the LDS-resident keys) and the
+    // digit passes start below them.
+    int b_first = 7;
     uint64_t prefix = 0;
+    if (cached) {
+        uint64_t kmin = EMPTY_KEY, kmax = 0;
+        for (uint32_t i = tid; i < n; i += SEL_THREADS) {
+            uint64_t k = sKeys[i];
+            if (k != EMPTY_KEY) { kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            uint64_t a = __shfl_xor(kmin, o), b2 = __shfl_xor(kmax, o);
+            kmin = a < kmin ? a : kmin;
+            kmax = b2 > kmax ? b2 : kmax;
+        }
+        if (lane == 0) { atomicMin(&sMinMax[0], kmin); atomicMax(&sMinMax[1], kmax); }
+        __syncthreads();
+        const uint64_t diff = sMinMax[0] ^ sMinMax[1];
+        if (diff) {
+            b_first = (63 - __clzll((long long)diff)) >> 3;        // highest byte in which two keys differ
+            if (b_first < 7) prefix = sMinMax[0] >> (8 * (b_first + 1));
+        } else {
+            b_first = 0;                                           // a single distinct key
+            prefix = sMinMax[0] >> 8;
+        }
+    }
     uint32_t remain = kk;
     uint32_t inbucket = nvalid;          // keys still matching the prefix
-    for (int b = 7; b >= 0; --b) {
+    for (int b = b_first; b >= 0; --b) {
         if (tid < 256) sHist[tid] = 0;
         __syncthreads();
         const int shift = 8 * b;
         // Scores are concentrated, so in the first passes nearly every key lands in one or two bins:
         // aggregate equal digits inside the wave (one LDS atomic per distinct digit) while many keys
         // still take part; plain atomics once the bucket is small.
-        const bool aggregate = (b == 7) && inbucket > 512;   // top byte: sign and exponent, usually one value
+        const bool aggregate = (b == b_first) && inbucket > 512;   // first digit examined: usually few distinct values
         for (uint32_t i = tid; i < n; i += SEL_THREADS) {
             uint64_t k = cached ? sKeys[i] : keys[i];
             if (!cached && has_lo && k <= lo) k = EMPTY_KEY;
-            bool in = (k != EMPTY_KEY) && (b == 7 || (k >> (shift + 8)) == prefix);
+            bool in = (k != EMPTY_KEY) && (b == 7 || (k >> (shift + 8)) == prefix);   // (all valid keys share a skipped prefix)
             uint32_t d = (uint32_t)(k >> shift) & 255u;
             if (aggregate) {
                 unsigned long long active = __ballot(in);
@@ -498,28 +520,35 @@ void launch_select(const SelectParams& p, uint32_t nq, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Exact re-rank of the kp candidates of each query + certification + final ordering.
-// One 128-thread workgroup per query, one candidate per thread.  Distances are computed
-// in the reference's exact operation order, so they are bit-identical to the CPU oracle.
-// Certification: every row NOT among the candidates has ranking score >= T (the kp-th
-// candidate's score).  From T we derive a lower bound LB on such a row's exact distance
-// (rounding-error bound eps); if the k-th exact distance is < LB, no
-// excluded row can enter the top k and the result is exact.  Otherwise cert[q] = 0 and
-// the host re-does that query with the exact scan.
+// Exact re-rank of the candidates of each query + certification + final ordering.
+// One 512-thread workgroup per query.  Candidates arrive sorted by ranking score; their distances are
+// computed in the reference's exact operation order (bit-identical to the CPU oracle), one candidate per
+// thread, rows staged through LDS in chunks.
+// ADAPTIVE DEPTH: the first kp_first candidates are re-ranked, then the result is tested: every row not
+// yet re-ranked has ranking score >= T (the score of the first candidate not re-ranked; the filter
+// threshold once the whole pool is used up).  From T a lower bound LB on such a row's exact distance
+// follows with the tier's error bound; if the k-th exact distance so far is < LB no other row
+// can enter the top k and the result is the oracle's.  Otherwise kp_step more candidates are re-ranked and
+// the test repeated, up to the kp candidates the select delivered; then cert[q] = 0 and the host hands
+// the query to the next tier.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rerank_kernel(RerankParams p) {
+constexpr uint32_t RR_MAX = 256;        // candidates per query at most
+constexpr uint32_t RR_THREADS = 512;
+
+__global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
     extern __shared__ __attribute__((aligned(16))) float sRows[];   // query row + `chunk` candidate rows
-    __shared__ uint32_t sDist[128];     // ordered exact distance
-    __shared__ uint64_t sId[128];
-    __shared__ uint32_t sRowIdx[128];
-    __shared__ uint32_t sAnyNan, sNanKey;
-    const uint32_t q = blockIdx.x, tid = threadIdx.x;
-    const uint32_t cnt = p.cand_cnt[q];
-    if (tid == 0) { sAnyNan = 0; sNanKey = 0; }
-    if (tid < 128) {
+    __shared__ uint32_t sDist[RR_MAX];    // ordered exact distance
+    __shared__ uint64_t sId[RR_MAX];
+    __shared__ uint32_t sRowIdx[RR_MAX];
+    __shared__ uint32_t sAnyNan, sNanKey, sState, sRealW[4];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t cnt = p.cand_cnt[q] < p.kp ? p.cand_cnt[q] : p.kp;
+    const uint64_t* cand = p.cand + (size_t)q * p.cand_stride;
+    if (tid == 0) { sAnyNan = 0; sNanKey = 0; sState = 0; }
+    if (tid < RR_MAX) {
         uint32_t row = 0xffffffffu;
         if (tid < cnt) {
-            uint64_t key = p.cand[(size_t)q * p.cand_stride + tid];
+            uint64_t key = cand[tid];
             row = (uint32_t)key;
             if ((uint32_t)(key >> 32) == 0u) sNanKey = 1u;      // approximate score was NaN (benign race)
             bool ok = row < p.n_rows && (p.rowmask ? ((p.rowmask[row >> 5] >> (row & 31)) & 1u) : true);
@@ -529,64 +558,152 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankParams p) {
         sDist[tid] = 0xffffffffu;
         sId[tid] = ~0ull;
     }
-    // stage the query and, chunk by chunk, the candidate rows in LDS (coalesced), then ONE thread per
-    // candidate folds in the reference's order; row stride is padded so 16 lanes' b128 reads tile the banks
+    // the query row in LDS; row stride padded so that 16 lanes' b128 reads tile the banks
     const uint32_t dimp = (p.dim + 3) & ~3u;
     const uint32_t ldp = p.lds_row_stride;
     const uint32_t chunk = p.lds_chunk;
     float* sQ = sRows;
     float* sR = sRows + ldp;
     const float* gq = p.qp + (size_t)q * p.ld;                    // zero padded up to ld >= dimp
-    for (uint32_t i = tid * 4; i < dimp; i += 1024) *reinterpret_cast<float4*>(sQ + i) = *reinterpret_cast<const float4*>(gq + i);
+    for (uint32_t i = tid * 4; i < dimp; i += RR_THREADS * 4) *reinterpret_cast<float4*>(sQ + i) = *reinterpret_cast<const float4*>(gq + i);
     __syncthreads();
-    const uint32_t vec_per_row = dimp / 4;
-    for (uint32_t c0 = 0; c0 < cnt; c0 += chunk) {
-        const uint32_t nthis = (cnt - c0 < chunk) ? cnt - c0 : chunk;
-        for (uint32_t r = tid >> 6; r < nthis; r += 4) {            // one wave per candidate row
-            const uint32_t row = sRowIdx[c0 + r];
-            if (row == 0xffffffffu) continue;
-            const float* src = p.rows + (size_t)row * p.ld;
-            float* dstr = sR + (size_t)r * ldp;
-            for (uint32_t c4 = tid & 63; c4 < vec_per_row; c4 += 64)
-                *reinterpret_cast<float4*>(dstr + 4 * c4) = *reinterpret_cast<const float4*>(src + 4 * c4);
-        }
-        __syncthreads();
-        if (tid < nthis) {
-            uint32_t row = sRowIdx[c0 + tid];
-            if (row != 0xffffffffu) {
-                float dist = exact_distance(p.metric, sQ, sR + (size_t)tid * ldp, p.dim, p.qnorm[q], p.nd[row]);
-                if (dist != dist) sAnyNan = 1u;
-                sDist[c0 + tid] = f32_to_ordered(dist);
-                sId[c0 + tid] = p.row_ids[row];
+    const uint32_t vpr = dimp / 4;                                // float4 per row
+    const uint32_t bpr = (vpr + 63) / 64;                         // 64-lane blocks per row
+    const uint32_t nwaves = RR_THREADS / 64;
+    const float qn_f = p.qnorm[q];
+
+    uint32_t processed = 0;
+    uint32_t target = cnt < p.kp_first ? cnt : p.kp_first;
+    uint32_t nout = 0;
+    uint32_t cert = 1;
+    while (true) {
+        // ---- exact distances of candidates [processed, target)
+        for (uint32_t c0 = processed; c0 < target; c0 += chunk) {
+            const uint32_t nthis = (target - c0 < chunk) ? target - c0 : chunk;
+            // stage: wave wv copies rows wv, wv+8, ... of the chunk; 8 independent 16-byte loads in flight per lane
+            const uint32_t rows_w = nthis > wv ? (nthis - wv + nwaves - 1) / nwaves : 0;
+            const uint32_t units = rows_w * bpr;
+            for (uint32_t u0 = 0; u0 < units; u0 += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t u = u0 + j;
+                    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (u < units) {
+                        const uint32_t r = wv + (u / bpr) * nwaves, c4 = (u % bpr) * 64 + lane;
+                        const uint32_t row = sRowIdx[c0 + r];
+                        if (c4 < vpr && row != 0xffffffffu)
+                            v[j] = *reinterpret_cast<const float4*>(p.rows + (size_t)row * p.ld + 4 * c4);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t u = u0 + j;
+                    if (u < units) {
+                        const uint32_t r = wv + (u / bpr) * nwaves, c4 = (u % bpr) * 64 + lane;
+                        if (c4 < vpr) *reinterpret_cast<float4*>(sR + (size_t)r * ldp + 4 * c4) = v[j];
+                    }
+                }
             }
-        }
-        __syncthreads();
-    }
-    // bitonic sort of 128 (dist, id) pairs, ascending
-    for (uint32_t size = 2; size <= 128; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            if (tid < 64) {
-                uint32_t lo = 2 * tid - (tid & (stride - 1));
-                uint32_t hi = lo + stride;
-                bool up = ((lo & size) == 0);
-                uint32_t da = sDist[lo], db = sDist[hi];
-                uint64_t ia = sId[lo], ib = sId[hi];
-                bool gt = da > db || (da == db && ia > ib);
-                if (gt == up) { sDist[lo] = db; sDist[hi] = da; sId[lo] = ib; sId[hi] = ia; }
+            __syncthreads();
+            if (tid < nthis) {
+                const uint32_t row = sRowIdx[c0 + tid];
+                if (row != 0xffffffffu) {
+                    float dist = exact_distance(p.metric, sQ, sR + (size_t)tid * ldp, p.dim, qn_f, p.nd[row]);
+                    if (dist != dist) sAnyNan = 1u;
+                    sDist[c0 + tid] = f32_to_ordered(dist);
+                    sId[c0 + tid] = p.row_ids[row];
+                }
             }
             __syncthreads();
         }
-    }
-    // number of real candidates (ineligible ones sorted to the end with id ~0)
-    uint32_t real = 0;
-    {
-        unsigned long long b0 = __ballot(tid < 128 && sId[tid & 127] != ~0ull);
-        __shared__ uint32_t sReal[2];
-        if ((tid & 63) == 0 && tid < 128) sReal[tid >> 6] = (uint32_t)__popcll(b0);
+        processed = target;
+        // ---- bitonic sort of the first P >= processed (dist, id) pairs, ascending; unused slots hold the maximum
+        uint32_t P = 32;
+        while (P < processed) P <<= 1;
+        for (uint32_t size = 2; size <= P; size <<= 1) {
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                if (tid < P / 2) {
+                    uint32_t lo = 2 * tid - (tid & (stride - 1));
+                    uint32_t hi = lo + stride;
+                    bool up = ((lo & size) == 0);
+                    uint32_t da = sDist[lo], db = sDist[hi];
+                    uint64_t ia = sId[lo], ib = sId[hi];
+                    bool gt = da > db || (da == db && ia > ib);
+                    if (gt == up) { sDist[lo] = db; sDist[hi] = da; sId[lo] = ib; sId[hi] = ia; }
+                }
+                __syncthreads();
+            }
+        }
+        // number of real candidates so far (ineligible ones sorted to the end with id ~0)
+        if (tid < RR_MAX) {
+            unsigned long long b0 = __ballot(tid < processed && sId[tid] != ~0ull);
+            if (lane == 0) sRealW[wv] = (uint32_t)__popcll(b0);
+        }
         __syncthreads();
-        real = sReal[0] + sReal[1];
+        const uint32_t real = sRealW[0] + sRealW[1] + sRealW[2] + sRealW[3];
+        nout = real < p.k ? real : p.k;
+        if (tid == 0) {
+            // ---- certification
+            uint32_t state = 1;                                   // 1 = finished
+            cert = 1;
+            bool have_T = false;
+            float T = 0.f;
+            if (processed < cnt) { T = ordered_to_f32((uint32_t)(cand[processed] >> 32)); have_T = true; }
+            else if (cnt == p.kp) { T = ordered_to_f32((uint32_t)(cand[p.kp - 1] >> 32)); have_T = true; }
+            else if (p.thr && p.thr[q] < __uint_as_float(0x7f800000u)) {
+                // the whole pool is re-ranked: every other row was rejected by the (finite) filter threshold
+                T = p.thr[q]; have_T = true;
+            }
+            if (have_T) {
+                bool ok = false;
+                if (nout == p.k && nout > 0 && !sNanKey && real == processed) {
+                    double ek = (double)ordered_to_f32(sDist[nout - 1]);
+                    double qn = (double)qn_f;
+                    double eps = (double)p.eps_coef;
+                    double ndmax = sqrt((double)__uint_as_float(p.nd2max_bits[0]));
+                    if (p.qerr) {
+                        // bf16 screening tier.  With e_q = q - bf16(q) (known) and e_d = d - bf16(d):
+                        //   dot(q,d) - dot(bf16 q, bf16 d) = e_q.d + bf16(q).e_d ,  |.| <= |e_q||d| + |bf16 q||e_d|   (Cauchy-Schwarz)
+                        // plus the f32 accumulation inside the MFMAs (c_acc |q||d|).  |bf16 q| <= 1.004 |q|; 1 % covers the f32
+                        // evaluation of the norms.  eps is the f32 tier's coefficient (oracle fold + fma chain).
+                        const double eq = (double)p.qerr[q];
+                        const double emax = sqrt((double)__uint_as_float(p.nd2max_bits[2]));
+                        const double rmax = sqrt((double)__uint_as_float(p.nd2max_bits[3]));
+                        const double cacc = (double)p.c_acc;
+                        if (p.metric == DOT) {
+                            const double E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
+                            ok = ek < (double)T - E - eps * qn * ndmax;
+                        } else if (p.metric == COSINE) {
+                            const double Ec = 1.01 * (eq / qn + 1.004 * rmax) + cacc;
+                            ok = ek < 1.0 + (double)T / qn - Ec - eps;
+                        } else {
+                            const double E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
+                            double s = qn + ndmax;
+                            ok = ek * ek < (double)T + qn * qn - 2.0 * E - eps * (s * s + ek * ek);
+                        }
+                    } else if (p.metric == DOT) {
+                        ok = ek < (double)T - eps * qn * ndmax;
+                    } else if (p.metric == COSINE) {
+                        ok = ek < 1.0 + (double)T / qn - eps;
+                    } else {
+                        double s = qn + ndmax;
+                        ok = ek * ek < (double)T + qn * qn - eps * (s * s + ek * ek);
+                    }
+                }
+                if (!ok) {
+                    cert = 0;
+                    // go deeper while candidates remain (a NaN score or an ineligible candidate cannot be repaired by depth)
+                    if (processed < cnt && !sNanKey && real == processed) state = 0;
+                }
+            }
+            sState = state;
+        }
+        __syncthreads();
+        if (sState) break;
+        target = processed + p.kp_step < cnt ? processed + p.kp_step : cnt;
+        __syncthreads();
     }
-    const uint32_t nout = real < p.k ? real : p.k;
     if (tid < p.k) {
         size_t o = (size_t)q * p.out_stride + tid;
         if (tid < nout) { p.out_ids[o] = sId[tid]; p.out_dists[o] = ordered_to_f32(sDist[tid]); }
@@ -595,66 +712,24 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankParams p) {
     if (tid == 0) {
         p.out_counts[q] = nout;
         if (sAnyNan) atomicOr(p.status, ST_NAN);
-        uint32_t cert = 1;
-        if (cnt == p.kp && nout > 0) {
-            // excluded rows may exist; T = score of the last candidate
-            float T = ordered_to_f32((uint32_t)(p.cand[(size_t)q * p.cand_stride + p.kp - 1] >> 32));
-            double ek = (double)ordered_to_f32(sDist[nout - 1]);
-            double qn = (double)p.qnorm[q];
-            double eps = (double)p.eps_coef;
-            double ndmax = sqrt((double)__uint_as_float(*p.nd2max_bits));
-            bool ok;
-            if (p.qerr) {
-                // bf16 screening tier.  With e_q = q - bf16(q) (known) and e_d = d - bf16(d):
-                //   dot(q,d) - dot(bf16 q, bf16 d) = e_q.d + bf16(q).e_d ,  |.| <= |e_q||d| + |bf16 q||e_d|   (Cauchy-Schwarz)
-                // plus the f32 accumulation inside the MFMAs (c_acc |q||d|).  |bf16 q| <= 1.004 |q|; 1 % covers the f32
-                // evaluation of the norms.  eps is the f32 tier's coefficient (oracle fold + fma chain).
-                const double eq = (double)p.qerr[q];
-                const double emax = sqrt((double)__uint_as_float(p.nd2max_bits[2]));
-                const double rmax = sqrt((double)__uint_as_float(p.nd2max_bits[3]));
-                const double cacc = (double)p.c_acc;
-                if (p.metric == DOT) {
-                    const double E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
-                    ok = ek < (double)T - E - eps * qn * ndmax;
-                } else if (p.metric == COSINE) {
-                    const double Ec = 1.01 * (eq / qn + 1.004 * rmax) + cacc;
-                    ok = ek < 1.0 + (double)T / qn - Ec - eps;
-                } else {
-                    const double E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
-                    double s = qn + ndmax;
-                    ok = ek * ek < (double)T + qn * qn - 2.0 * E - eps * (s * s + ek * ek);
-                }
-            } else if (p.metric == DOT) {
-                ok = ek < (double)T - eps * qn * ndmax;
-            } else if (p.metric == COSINE) {
-                ok = ek < 1.0 + (double)T / qn - eps;
-            } else {
-                double s = qn + ndmax;
-                ok = ek * ek < (double)T + qn * qn - eps * (s * s + ek * ek);
-            }
-            // a NaN approximate score next to a non-NaN exact one, or fewer real rows than
-            // asked for while the candidate list was full, cannot be certified either
-            if (!ok || sNanKey || real < p.kp) cert = 0;
-            if (nout < p.k) cert = 0;
-        } else if (cnt < p.kp && p.thr && p.thr[q] < __uint_as_float(0x7f800000u)) {
-            // fewer candidates than asked for although a finite threshold (met by >= kp sampled rows) was in force:
-            // the filter pass and the sample disagree -- never certify that
-            cert = 0;
-        }
         p.cert[q] = cert;
+        if (p.depth) p.depth[q] = processed;
     }
 }
 void launch_rerank(const RerankParams& p, uint32_t nq, hipStream_t s) {
     if (!nq) return;
     // LDS plan: query row + `chunk` candidate rows of padded stride (chunk = largest power of two that fits)
     RerankParams q = p;
+    if (q.kp > RR_MAX) q.kp = RR_MAX;
+    if (q.kp_first == 0 || q.kp_first > q.kp) q.kp_first = q.kp;
+    if (q.kp_step == 0) q.kp_step = 32;
     uint32_t dimp = (p.dim + 3) & ~3u;
     q.lds_row_stride = dimp + ((dimp % 8 == 0) ? 4 : 0);
     uint32_t chunk = 32;
     while (chunk > 1 && (size_t)(chunk + 1) * q.lds_row_stride * 4 > 150 * 1024) chunk >>= 1;
     q.lds_chunk = chunk;
     size_t lds = (size_t)(chunk + 1) * q.lds_row_stride * 4;   // dim <= ~19000 fits with chunk = 1
-    hipLaunchKernelGGL(rerank_kernel, dim3(nq), dim3(256), lds, s, q);
+    hipLaunchKernelGGL(rerank_kernel, dim3(nq), dim3(RR_THREADS), lds, s, q);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
         if (SAMPLE) {
             uint32_t j = (tile_first + t * tile_step) * TR + rt;
             if (j >= p.n_sample) j = p.n_sample - 1;
-            return p.n_sample >= p.n_rows ? j : (uint32_t)(((uint64_t)j * p.n_rows) / p.n_sample);
+            return (uint32_t)(((uint64_t)j * p.n_rows) >> p.sample_shift);      // n_sample = 2^sample_shift <= n_rows
         } else {
             const uint32_t r = r0 + t * TR + rt;
             return r > last_row ? last_row : r;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
                 if (SAMPLE) {
                     const uint32_t sj = sj0 + rt;
                     in = sj < p.n_sample;
-                    const uint32_t row = p.n_sample >= p.n_rows ? sj : (uint32_t)(((uint64_t)sj * p.n_rows) / p.n_sample);
+                    const uint32_t row = (uint32_t)(((uint64_t)sj * p.n_rows) >> p.sample_shift);
                     bit = row & 31;
                 } else {
                     in = tr0 + rt < r1;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
                 }
                 val[m] = __ballot(in && ((sMaskW[par * TR + rt] >> bit) & 1u));
             }
-            uint64_t min_a = EMPTY_KEY, min_b = EMPTY_KEY;
+            uint32_t best_a = 0xffffffffu, best_b = 0xffffffffu, brow_a = 0xffffffffu, brow_b = 0xffffffffu;
             const float* al = sAlpha + par * TR + wr * 128 + 4 * h;
             const float* be = sBeta + par * TR + wr * 128 + 4 * h;
 #pragma unroll
@@ -323,13 +323,11 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
         const float sa_ = fmaf(acc[i][0][4 * j + (E)], (AC), (BC));                                    \
         const float sb_ = fmaf(acc[i][1][4 * j + (E)], (AC), (BC));                                    \
         if (SAMPLE) {                                                                                  \
-            if (ok_) {                                                                                 \
-                uint32_t sj_ = sj0 + rowb + 8 * j + (E);                                               \
-                const uint32_t row_ = p.n_sample >= p.n_rows ? sj_ : (uint32_t)(((uint64_t)sj_ * p.n_rows) / p.n_sample); \
-                const uint64_t ka_ = make_key(sa_, row_), kb_ = make_key(sb_, row_);                   \
-                min_a = ka_ < min_a ? ka_ : min_a;                                                     \
-                min_b = kb_ < min_b ? kb_ : min_b;                                                     \
-            }                                                                                          \
+            /* smallest (ordered score, tile-row) of the lane's rows; a NaN score orders first (key 0) */      \
+            const uint32_t oa_ = (sa_ != sa_) ? 0u : f32_to_ordered(sa_);                              \
+            const uint32_t ob_ = (sb_ != sb_) ? 0u : f32_to_ordered(sb_);                              \
+            if (ok_ && oa_ < best_a) { best_a = oa_; brow_a = rowb + 8 * j + (E); }                    \
+            if (ok_ && ob_ < best_b) { best_b = ob_; brow_b = rowb + 8 * j + (E); }                    \
         } else {                                                                                       \
             if (!(sa_ > thr_a) && ok_) {                                                               \
                 if (pcnt_a < p.capl) pool_a[pcnt_a] = make_raw_key(sa_, tr0 + rowb + 8 * j + (E));     \
@@ -351,8 +349,10 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
             if (SAMPLE) {
                 // one group minimum per (tile, row half, lane half) and query
                 const uint32_t g = (((tile_first + tile * tile_step) * 2 + wr) * 2 + h);
-                p.minkeys[(size_t)q_a * p.minkey_stride + g] = min_a;
-                p.minkeys[(size_t)q_b * p.minkey_stride + g] = min_b;
+                const uint32_t ra_ = brow_a == 0xffffffffu ? 0u : (uint32_t)(((uint64_t)(sj0 + brow_a) * p.n_rows) >> p.sample_shift);
+                const uint32_t rb_ = brow_b == 0xffffffffu ? 0u : (uint32_t)(((uint64_t)(sj0 + brow_b) * p.n_rows) >> p.sample_shift);
+                p.minkeys[(size_t)q_a * p.minkey_stride + g] = brow_a == 0xffffffffu ? EMPTY_KEY : (((uint64_t)best_a << 32) | ra_);
+                p.minkeys[(size_t)q_b * p.minkey_stride + g] = brow_b == 0xffffffffu ? EMPTY_KEY : (((uint64_t)best_b << 32) | rb_);
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)

@@ -365,11 +365,26 @@ float c_acc_bf16(const Index* ix) {
     return (float)c;
 }
 
-// candidates kept per query by the bf16 screening tier (0: k too large for it)
-uint32_t pick_kp_bf16(size_t k) {
-    if (k <= 16) return 64;
-    if (k <= 64) return 128;
-    return 0;
+// bf16 screening tier: the select delivers up to 256 candidates per query, sorted by score, and the re-rank goes
+// through them adaptively (rerank_kernel): first round_up(k + 22, 32), then 32 more per round until the result is
+// certified.  The filter threshold is the kt-th smallest of the M = S/64 group minima of an S-row sample (at least
+// kt rows pass it); S = 2^s is sized so that about 2000 keys per query pass, and kt <= M/4 so that the kt smallest
+// minima come from (nearly) distinct groups.
+constexpr uint32_t BF16_MIN_ROWS = 65536;
+struct Bf16Plan { uint32_t kp = 0, S = 0, shift = 0, kt = 0; };
+Bf16Plan plan_bf16(uint32_t n, size_t k) {
+    Bf16Plan pl;
+    if (n < BF16_MIN_ROWS || k > 112) return pl;
+    const uint32_t want_kt = std::min<uint32_t>(128u, round_up((uint32_t)k + 22u, 32u));
+    uint64_t S = std::min<uint64_t>(65536u, std::max<uint64_t>(16384u, pow2_ceil((uint64_t)n / 16u)));
+    if (const char* e = getenv("VDB_SAMPLE16")) S = pow2_ceil(std::max(256, atoi(e)));
+    while (S / 256u < want_kt && 2 * S <= n / 2) S *= 2;
+    while (S > n) S /= 2;
+    uint32_t kt = std::min<uint32_t>(128u, (uint32_t)(S / 256u));
+    if (kt < k + 1 || kt < 16) return pl;
+    pl.kp = 256; pl.S = (uint32_t)S; pl.kt = kt;
+    while ((1ull << pl.shift) < S) ++pl.shift;
+    return pl;
 }
 
 uint32_t pick_kp(size_t k) {
@@ -518,22 +533,19 @@ int pass_f32(Index* ix, hipStream_t s, const float* qp, const float* qnorm, floa
 // Same structure, with the scores of the HBM-bound bf16 kernel (kernels_fused_bf16.hip): group minima of a row
 // sample -> per-query threshold -> one pass over all rows keeping the keys under the threshold -> the kp smallest
 // keys -> exact re-rank, certified with the bf16 error bound.  Queries come from ix->w_qp / w_qb / w_qnorm.
-int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, uint32_t kp, const uint32_t* d_rowmask,
+int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& pl, const uint32_t* d_rowmask,
               uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, uint32_t* d_cert, uint32_t* d_ovf,
               uint32_t* d_status) {
     int rc;
     const uint32_t n = ix->n_uploaded, ld = ix->ld;
-    // sample size: the filter pass keeps about n*kp/S keys per query (target ~2000), 64 <= groups <= 16384
-    uint32_t S = (uint32_t)std::min<uint64_t>(65536u, std::max<uint64_t>(4096u, pow2_ceil((uint64_t)n * kp / 2048u)));
-    if (const char* e = getenv("VDB_SAMPLE16")) S = std::max(256, atoi(e));
-    S = std::min(S, n / 256u * 256u);
+    const uint32_t S = pl.S, kp = pl.kp, KT = pl.kt;
     const uint32_t M = vdb::fused_bf16_sample_groups(S);
     const uint32_t capl = 64;
     const uint32_t n_wg = std::min<uint32_t>((uint32_t)ix->n_cu, (n + 31) / 32);
     const uint32_t n_sub = vdb::fused_bf16_subpools_per_query(n_wg);
     if ((rc = ix->w_dense.ensure((size_t)SUPER * M))) return rc;
     if ((rc = ix->w_cand.ensure((size_t)SUPER * kp))) return rc;
-    if ((rc = ix->w_samp.ensure((size_t)SUPER * kp))) return rc;
+    if ((rc = ix->w_samp.ensure((size_t)SUPER * std::max(kp, KT)))) return rc;
     if ((rc = ix->w_pool.ensure((size_t)SUPER * n_sub * capl))) return rc;
     if ((rc = ix->w_subcnt.ensure((size_t)SUPER * n_sub))) return rc;
     uint32_t* d_cnt_a = ix->w_cnt.p;
@@ -546,12 +558,12 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, uint32_t kp, cons
         fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w_qb.p + (size_t)q0 * ld;
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
         fp.thr = ix->w_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
-        fp.n_sample = S; fp.minkeys = ix->w_dense.p; fp.minkey_stride = M;
+        fp.n_sample = S; fp.sample_shift = pl.shift; fp.minkeys = ix->w_dense.p; fp.minkey_stride = M;
         vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);
 
         vdb::SelectParams sp{};
-        sp.keys = ix->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = kp;
-        sp.out_stride = kp; sp.out_keys = ix->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->w_thr.p + q0; sp.ovf = nullptr;
+        sp.keys = ix->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = KT;
+        sp.out_stride = KT; sp.out_keys = ix->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->w_thr.p + q0; sp.ovf = nullptr;
         vdb::launch_select(sp, nb, s);
 
         if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
@@ -581,6 +593,7 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, uint32_t kp, cons
         rp.out_counts = d_out_counts + q0; rp.out_stride = (uint32_t)k; rp.cert = d_cert + q0; rp.status = d_status;
         rp.thr = ix->w_thr.p + q0;
         rp.qerr = ix->w_qerr.p + q0; rp.c_acc = c_acc_bf16(ix);
+        rp.kp_first = round_up((uint32_t)k + 22u, 32u); rp.kp_step = 32;
         vdb::launch_rerank(rp, nb, s);
     }
     return VDB_OK;
@@ -655,7 +668,7 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
     // ---- queries: zero-padded copy + exact-order norms
     {
         uint16_t* qb = nullptr;
-        if (ix->screen && n > SMALL_N && pick_kp_bf16(k)) {
+        if (ix->screen && plan_bf16(n, k).kp) {
             if ((rc = ix->w_qb.ensure((size_t)bp_all * ld))) return rc;
             if ((rc = ix->w_qerr.ensure(bp_all))) return rc;
             qb = ix->w_qb.p;
@@ -665,7 +678,7 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
         vdb::launch_query_prep(qp, s);
     }
 
-    if (kp == 0) {
+    if (kp == 0 && !(ix->screen && plan_bf16(n, k).kp)) {
         // large k: exact scan for every query
         HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -685,13 +698,13 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
 
     // ---- tiers.  Large indexes: the bf16 screening tier first (HBM-bound pass), the queries it cannot certify
     // are re-run as a compact block by the f32 MFMA tier; whatever that cannot certify goes to the exact scan.
-    const bool small = n <= SMALL_N;
-    const uint32_t kp16 = (ix->screen && !small) ? pick_kp_bf16(k) : 0;
+    const Bf16Plan pl16 = ix->screen ? plan_bf16(n, k) : Bf16Plan{};
+    const uint32_t kp16 = pl16.kp;
     if ((rc = ix->w_cnt.ensure(4 * SUPER + 16))) return rc;
     if (kp16) {
         ix->stats[8] = 1;
         ix->stats[5] = kp16;
-        if ((rc = pass_bf16(ix, s, nq32, k, kp16, d_rowmask, d_out_ids, d_out_dists, d_out_counts, d_cert, d_ovf, d_status)))
+        if ((rc = pass_bf16(ix, s, nq32, k, pl16, d_rowmask, d_out_ids, d_out_dists, d_out_counts, d_cert, d_ovf, d_status)))
             return rc;
     } else {
         if ((rc = pass_f32(ix, s, ix->w_qp.p, ix->w_qnorm.p, ix->w_thr.p, nq32, k, kp, d_rowmask, d_out_ids, d_out_dists,
