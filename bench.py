@@ -11,7 +11,8 @@ GPU, RCCL): local search -> one all-gather of the partial top-k -> merge ("scali
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement), with
-"roofline" (fused MFMA kernel, HIP-event timed on its launch stream) and "cpu_baseline"
+"roofline" (the dominant kernel, HIP-event timed on its launch stream), "f32_mfma_tier" (the f32-input MFMA tier
+measured on the same index in the same run; results identical) and "cpu_baseline"
 (the CPU oracle = port of the reference algorithm, 1 core, bounded query sample).
 """
 import argparse
@@ -70,6 +71,8 @@ def main():
     ap.add_argument("--metric", type=int, default=METRIC)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-f32-tier", action="store_true", help="skip the side measurement of the f32 MFMA tier")
+    ap.add_argument("--screen", type=int, default=1, help="1: bf16 screening tier first (default); 0: f32 MFMA tier only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
     ap.add_argument("--filter-mod", type=int, default=0, help="config-4 style pre-filter: only ids with id %% m == 0 are eligible")
     args = ap.parse_args()
@@ -112,6 +115,7 @@ def main():
         index.add_bulk_device(part.data_ptr(), b - a, dim, first_id=a)
         del block, part
     index.flush()
+    index.set_screen(args.screen)
     queries = gen_queries(B, dim, device)
     mask_t, mask_bits = None, 0
     if args.filter_mod > 1:
@@ -147,31 +151,77 @@ def main():
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     qps = B * args.steps / elapsed
     stats = index.last_stats()
+    out = tuple(t.clone() for t in out)          # the search reuses its output tensors; keep this step's results
 
-    # ---- roofline of the dominant kernel (fused MFMA score+filter), HIP events on its launch stream
-    index.set_profile(True)
-    kern_ns = []
-    for _ in range(max(3, min(args.steps, 10))):
-        step()
-        kern_ns.append(index.last_stats()["fused_kernel_ns"])
-    index.set_profile(False)
-    kern_ms = float(np.mean(kern_ns)) / 1e6
+    # ---- roofline of the dominant kernel, HIP events on its launch stream (vdb_flat_set_profile).
+    # Default path: the bf16 screening kernel streams the f32 rows once -> bound by HBM; algorithmic bytes per
+    # launch = 4*N*d + 4*B*d.  The f32 MFMA tier (set_screen(0)) is measured beside it in the same
+    # run: bound by the f32-input MFMA peak, algorithmic FLOPs 2*B*N*d.
+    def kernel_ms_of(n_iter):
+        index.set_profile(True)
+        ns = []
+        for _ in range(n_iter):
+            step()
+            ns.append(index.last_stats()["fused_kernel_ns"])
+        index.set_profile(False)
+        return float(np.mean(ns)) / 1e6
+
+    n_prof = max(3, min(args.steps, 10))
+    kern_ms = kernel_ms_of(n_prof)
     local_rows = hi - lo
     alg_flops = 2.0 * B * local_rows * dim                      # 2*B*N*d per launch
     alg_bytes = 4.0 * local_rows * dim + 4.0 * B * dim
-    achieved_tf = alg_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    screened = bool(stats.get("bf16_screen"))
     traffic = None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp) and world == 1 and n_rows == N_ROWS:
         try:
-            traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tp))
+            traffic = tj.get("hbm_bytes_per_launch_bf16_screen" if screened else "hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                "kernel": "fused_score_filter_dma3_kernel (8 waves, 128 rows x 256 queries, 3-image LDS-DMA ring)", "kernel_ms": round(kern_ms, 4),
-                "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
-                "hbm_frac_algorithmic": round(alg_bytes / (kern_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if kern_ms > 0 else None}
+    achieved_tf = alg_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    achieved_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    if screened:
+        roofline = {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(achieved_gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
+                    "kernel": "fused_bf16_kernel<false> (8 waves, 256 rows x 256 queries, f32 rows by LDS-DMA into a 3-image "
+                              "ring, bf16 MFMA 32x32x16 scores, threshold filter)",
+                    "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                    "algorithmic_flops_per_launch": alg_flops,
+                    "bf16_mfma_tflops": round(achieved_tf, 1)}
+    else:
+        roofline = {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "kernel": "fused_score_filter_dma3_kernel (8 waves, 128 rows x 256 queries, 3-image LDS-DMA ring)", "kernel_ms": round(kern_ms, 4),
+                    "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
+                    "hbm_frac_algorithmic": round(achieved_gbs / PEAK_HBM_GBS, 4) if kern_ms > 0 else None}
+    # the f32 MFMA tier on the same index and queries (only when the default path screened)
+    f32_tier = None
+    if screened and not args.no_f32_tier:
+        index.set_screen(0)
+        for _ in range(2):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        n_f32 = max(3, min(args.steps, 10))
+        for _ in range(n_f32):
+            out_f32 = step()
+        barrier()
+        el = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        k32 = kernel_ms_of(3)
+        tf32 = alg_flops / (k32 * 1e-3) / 1e12 if k32 > 0 else 0.0
+        same = bool(torch.equal(out_f32[0], out[0]) and torch.equal(out_f32[1].view(torch.int32), out[1].view(torch.int32)))
+        f32_tier = {"value": round(B * n_f32 / el, 2), "unit": "queries/s", "ms_per_step": round(1e3 * el / n_f32, 4),
+                    "results_identical_to_default_path": same,
+                    "roofline": {"bound": "mfma", "achieved": round(tf32, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(tf32 / PEAK_F32_MFMA_TFLOPS, 4), "kernel_ms": round(k32, 4),
+                                 "kernel": "fused_score_filter_dma3_kernel (f32-input MFMA 32x32x2, 3-image LDS-DMA ring)"}}
+        index.set_screen(1)
 
     # ---- cpu_baseline (rank 0, N=1 only): the oracle restatement of the reference, 1 core, bounded sample
     cpu = None
@@ -224,7 +274,8 @@ def main():
             "metric": "QPS, FlatIndex brute-force kNN 1Mx768 f32 cosine batch=256 k=10 (recall@10 vs reference algorithm)",
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (rows, queries, distances and the exact re-rank are f32; candidate screening scores on bf16 MFMA, certified)"
+                     if screened else "f32", "data": "synthetic",
             "config": {"workload": "FlatIndex 1M x 768 f32, cosine, batch=256 queries, k=10 (BASELINE configs[1])",
                        "n_rows": n_rows, "dim": dim, "batch": B, "k": k,
                        "distance": ["euclidean", "cosine", "dot"][args.metric],
@@ -234,6 +285,7 @@ def main():
             "recall_at_10": recall,
             "path_stats": stats,
             "roofline": roofline,
+            "f32_mfma_tier": f32_tier,
             "cpu_baseline": cpu,
         }
         if parity_n is not None:
