@@ -6,6 +6,8 @@
 // (src/distance.rs:37-73, src/vector.rs:35-37).
 #include "kernels.h"
 
+#include <algorithm>
+
 #pragma clang fp contract(off)
 
 namespace vdb {
@@ -202,7 +204,13 @@ __global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepParams p) {
         float v = (q < p.nq && i < p.dim) ? src[i] : 0.0f;
         dst[i] = v;
         sQrow[i] = v;
-        if (p.qb) p.qb[(size_t)q * p.ld + i] = __builtin_bit_cast(uint16_t, (__bf16)v);   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+        if (p.qb) {
+            // bf16 copy (v_cvt_pk_bf16_f32: RNE, NaN stays NaN) in the LDS image order of the screening kernel: per pass of
+            // 256 queries and per K stage of 32 one 16 KB image, query r = 64 B, its 16-byte chunk x at position x ^ ((r>>2)&3)
+            const uint32_t pass = q >> 8, r = q & 255u, ks = i >> 5, x = (i >> 3) & 3u, e = i & 7u;
+            const size_t img = ((size_t)pass * (p.ld >> 5) + ks) * (256u * 32u);
+            p.qb[img + r * 32u + ((x ^ ((r >> 2) & 3u)) << 3) + e] = __builtin_bit_cast(uint16_t, (__bf16)v);
+        }
     }
     if (p.qb) {
         // |q - bf16(q)|: any summation order will do (it is an upper bound, rounded up below)
@@ -532,6 +540,38 @@ void launch_select(const SelectParams& p, uint32_t nq, hipStream_t s) {
 // the test repeated, up to the kp candidates the select delivered; then cert[q] = 0 and the host hands
 // the query to the next tier.
 // ---------------------------------------------------------------------------------------------
+// The certification test: every row not re-ranked has ranking score >= T; is the k-th exact distance ek below the
+// lower bound that T implies for such a row's exact distance?  (DESIGN.md "certified top-k")
+__device__ __forceinline__ bool cert_test(const RerankParams& p, uint32_t q, float T, double ek, double qn) {
+    const double eps = (double)p.eps_coef;
+    const double ndmax = sqrt((double)__uint_as_float(p.nd2max_bits[0]));
+    if (p.qerr) {
+        // bf16 screening tier.  With e_q = q - bf16(q) (known) and e_d = d - bf16(d):
+        //   dot(q,d) - dot(bf16 q, bf16 d) = e_q.d + bf16(q).e_d ,  |.| <= |e_q||d| + |bf16 q||e_d|   (Cauchy-Schwarz)
+        // plus the f32 accumulation inside the MFMAs (c_acc |q||d|).  |bf16 q| <= 1.004 |q|; 1 % covers the f32
+        // evaluation of the norms.  eps is the f32 tier's coefficient (oracle fold + fma chain).
+        const double eq = (double)p.qerr[q];
+        const double emax = sqrt((double)__uint_as_float(p.nd2max_bits[2]));
+        const double rmax = sqrt((double)__uint_as_float(p.nd2max_bits[3]));
+        const double cacc = (double)p.c_acc;
+        if (p.metric == DOT) {
+            const double E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
+            return ek < (double)T - E - eps * qn * ndmax;
+        } else if (p.metric == COSINE) {
+            const double Ec = 1.01 * (eq / qn + 1.004 * rmax) + cacc;
+            return ek < 1.0 + (double)T / qn - Ec - eps;
+        } else {
+            const double E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
+            const double s = qn + ndmax;
+            return ek * ek < (double)T + qn * qn - 2.0 * E - eps * (s * s + ek * ek);
+        }
+    }
+    if (p.metric == DOT) return ek < (double)T - eps * qn * ndmax;
+    if (p.metric == COSINE) return ek < 1.0 + (double)T / qn - eps;
+    const double s = qn + ndmax;
+    return ek * ek < (double)T + qn * qn - eps * (s * s + ek * ek);
+}
+
 constexpr uint32_t RR_MAX = 256;        // candidates per query at most
 constexpr uint32_t RR_THREADS = 512;
 
@@ -540,11 +580,11 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
     __shared__ uint32_t sDist[RR_MAX];    // ordered exact distance
     __shared__ uint64_t sId[RR_MAX];
     __shared__ uint32_t sRowIdx[RR_MAX];
-    __shared__ uint32_t sAnyNan, sNanKey, sState, sRealW[4];
+    __shared__ uint32_t sAnyNan, sNanKey, sNext, sRealW[4];
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t cnt = p.cand_cnt[q] < p.kp ? p.cand_cnt[q] : p.kp;
     const uint64_t* cand = p.cand + (size_t)q * p.cand_stride;
-    if (tid == 0) { sAnyNan = 0; sNanKey = 0; sState = 0; }
+    if (tid == 0) { sAnyNan = 0; sNanKey = 0; sNext = 0; }
     if (tid < RR_MAX) {
         uint32_t row = 0xffffffffu;
         if (tid < cnt) {
@@ -643,66 +683,43 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
         __syncthreads();
         const uint32_t real = sRealW[0] + sRealW[1] + sRealW[2] + sRealW[3];
         nout = real < p.k ? real : p.k;
-        if (tid == 0) {
-            // ---- certification
-            uint32_t state = 1;                                   // 1 = finished
-            cert = 1;
+        // ---- certification / how much deeper to go
+        const bool clean = !sNanKey && real == processed;          // no NaN score, no ineligible candidate so far
+        const bool can_test = clean && nout == p.k && nout > 0;
+        const double ek = can_test ? (double)ordered_to_f32(sDist[nout - 1]) : 0.0;
+        const double qn = (double)qn_f;
+        if (processed < cnt) {
+            // every candidate not yet re-ranked tests "would the result be certified if the re-rank stopped just
+            // before me": the first one that says yes is where the next round ends (ek can only shrink meanwhile)
+            if (tid == 0) sNext = 0xffffffffu;
+            __syncthreads();
+            if (can_test && tid >= processed && tid < cnt) {
+                const float T = ordered_to_f32((uint32_t)(cand[tid] >> 32));
+                if (cert_test(p, q, T, ek, qn)) atomicMin(&sNext, tid);
+            }
+            __syncthreads();
+            const uint32_t m = sNext;
+            if (can_test && m == processed) { cert = 1; break; }   // certified at this depth
+            if (!clean) { cert = 0; break; }                        // depth cannot repair a NaN score or an ineligible candidate
+            if (can_test && m != 0xffffffffu) target = m;           // re-rank exactly up to the first certifying candidate
+            else if (can_test) target = cnt;                        // none certifies: take the whole list, test against what lies beyond
+            else target = processed + p.kp_step < cnt ? processed + p.kp_step : cnt;   // fewer than k real rows so far
+            __syncthreads();
+            continue;
+        }
+        // the whole candidate list is re-ranked
+        {
             bool have_T = false;
             float T = 0.f;
-            if (processed < cnt) { T = ordered_to_f32((uint32_t)(cand[processed] >> 32)); have_T = true; }
-            else if (cnt == p.kp) { T = ordered_to_f32((uint32_t)(cand[p.kp - 1] >> 32)); have_T = true; }
+            if (cnt == p.kp) { T = ordered_to_f32((uint32_t)(cand[p.kp - 1] >> 32)); have_T = true; }
             else if (p.thr && p.thr[q] < __uint_as_float(0x7f800000u)) {
                 // the whole pool is re-ranked: every other row was rejected by the (finite) filter threshold
                 T = p.thr[q]; have_T = true;
             }
-            if (have_T) {
-                bool ok = false;
-                if (nout == p.k && nout > 0 && !sNanKey && real == processed) {
-                    double ek = (double)ordered_to_f32(sDist[nout - 1]);
-                    double qn = (double)qn_f;
-                    double eps = (double)p.eps_coef;
-                    double ndmax = sqrt((double)__uint_as_float(p.nd2max_bits[0]));
-                    if (p.qerr) {
-                        // bf16 screening tier.  With e_q = q - bf16(q) (known) and e_d = d - bf16(d):
-                        //   dot(q,d) - dot(bf16 q, bf16 d) = e_q.d + bf16(q).e_d ,  |.| <= |e_q||d| + |bf16 q||e_d|   (Cauchy-Schwarz)
-                        // plus the f32 accumulation inside the MFMAs (c_acc |q||d|).  |bf16 q| <= 1.004 |q|; 1 % covers the f32
-                        // evaluation of the norms.  eps is the f32 tier's coefficient (oracle fold + fma chain).
-                        const double eq = (double)p.qerr[q];
-                        const double emax = sqrt((double)__uint_as_float(p.nd2max_bits[2]));
-                        const double rmax = sqrt((double)__uint_as_float(p.nd2max_bits[3]));
-                        const double cacc = (double)p.c_acc;
-                        if (p.metric == DOT) {
-                            const double E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
-                            ok = ek < (double)T - E - eps * qn * ndmax;
-                        } else if (p.metric == COSINE) {
-                            const double Ec = 1.01 * (eq / qn + 1.004 * rmax) + cacc;
-                            ok = ek < 1.0 + (double)T / qn - Ec - eps;
-                        } else {
-                            const double E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
-                            double s = qn + ndmax;
-                            ok = ek * ek < (double)T + qn * qn - 2.0 * E - eps * (s * s + ek * ek);
-                        }
-                    } else if (p.metric == DOT) {
-                        ok = ek < (double)T - eps * qn * ndmax;
-                    } else if (p.metric == COSINE) {
-                        ok = ek < 1.0 + (double)T / qn - eps;
-                    } else {
-                        double s = qn + ndmax;
-                        ok = ek * ek < (double)T + qn * qn - eps * (s * s + ek * ek);
-                    }
-                }
-                if (!ok) {
-                    cert = 0;
-                    // go deeper while candidates remain (a NaN score or an ineligible candidate cannot be repaired by depth)
-                    if (processed < cnt && !sNanKey && real == processed) state = 0;
-                }
-            }
-            sState = state;
+            cert = 1;
+            if (have_T && !(can_test && cert_test(p, q, T, ek, qn))) cert = 0;
         }
-        __syncthreads();
-        if (sState) break;
-        target = processed + p.kp_step < cnt ? processed + p.kp_step : cnt;
-        __syncthreads();
+        break;
     }
     if (tid < p.k) {
         size_t o = (size_t)q * p.out_stride + tid;
@@ -725,8 +742,8 @@ void launch_rerank(const RerankParams& p, uint32_t nq, hipStream_t s) {
     if (q.kp_step == 0) q.kp_step = 32;
     uint32_t dimp = (p.dim + 3) & ~3u;
     q.lds_row_stride = dimp + ((dimp % 8 == 0) ? 4 : 0);
-    uint32_t chunk = 32;
-    while (chunk > 1 && (size_t)(chunk + 1) * q.lds_row_stride * 4 > 150 * 1024) chunk >>= 1;
+    uint32_t chunk = (uint32_t)std::min<size_t>(64, (150 * 1024) / ((size_t)q.lds_row_stride * 4));
+    chunk = chunk > 1 ? chunk - 1 : 1;                          // one slot is the query row; folds run on the lanes of ONE wave
     q.lds_chunk = chunk;
     size_t lds = (size_t)(chunk + 1) * q.lds_row_stride * 4;   // dim <= ~19000 fits with chunk = 1
     hipLaunchKernelGGL(rerank_kernel, dim3(nq), dim3(RR_THREADS), lds, s, q);

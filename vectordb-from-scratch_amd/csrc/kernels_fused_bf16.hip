@@ -133,12 +133,10 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
         const uint32_t rt = 32 * w + 8 * j + a_pr;                      // row inside the tile
         a_chunk[j] = (a_pp ^ ((rt >> 1) & 7)) * 16;
     }
-    uint32_t ob[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const uint32_t qr = 32 * w + 16 * j + b_pr;                     // query inside the tile
-        ob[j] = qr * ld * 2 + (b_pp ^ ((qr >> 2) & 3)) * 16;
-    }
+    // (the queries are stored by query_prep in exactly this image order, one 16 KB image per K stage: a wave's
+    // query piece is 1 KB of CONTIGUOUS global memory -- 8 full 128-byte requests instead of 16 scattered 64-byte ones)
+    const uint32_t ob[2] = {(2 * w) * 1024 + lane * 16, (2 * w + 1) * 1024 + lane * 16};
+    (void)b_pr; (void)b_pp;
     const char* aptr[4];                                                // row pieces of the tile being fetched
     auto tile_rows_of = [&](uint32_t t, uint32_t rt) -> uint32_t {      // device row of tile-row rt of local tile t
         if (SAMPLE) {
@@ -166,18 +164,26 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
 #define VDB_DMA(GP, IMG, LOFF)                                                                         \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"                     \
                  :: "s"((uint32_t)(uintptr_t)(lds_ptr_t)((IMG) + (LOFF))), "v"((const void*)(GP)) : "memory", "m0")
+    // rows are read once per launch: non-temporal, so that they do not push the queries out of the L2
+#define VDB_DMA_NT(GP, IMG, LOFF)                                                                      \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt"                  \
+                 :: "s"((uint32_t)(uintptr_t)(lds_ptr_t)((IMG) + (LOFF))), "v"((const void*)(GP)) : "memory", "m0")
 #define VDB_ISSUE(IMG, KSI)                                                                            \
     {                                                                                                  \
         const uint32_t la_ = (4 * w) * 1024;                                                           \
         const uint32_t lb_ = A_BYTES + (2 * w) * 1024;                                                 \
         const uint32_t ka_ = (KSI) * (KSTAGE * 4);                                                     \
-        const uint32_t kb_ = (KSI) * (KSTAGE * 2);                                                     \
-        VDB_DMA(aptr[0] + ka_, IMG, la_);                                                              \
-        VDB_DMA(aptr[1] + ka_, IMG, la_ + 1024);                                                       \
-        VDB_DMA(aptr[2] + ka_, IMG, la_ + 2048);                                                       \
-        VDB_DMA(aptr[3] + ka_, IMG, la_ + 3072);                                                       \
+        const uint32_t kb_ = (KSI) * B_BYTES;                                                          \
+        if (!(p.ablate & 2u)) {                                                                        \
+        VDB_DMA_NT(aptr[0] + ka_, IMG, la_);                                                           \
+        VDB_DMA_NT(aptr[1] + ka_, IMG, la_ + 1024);                                                    \
+        VDB_DMA_NT(aptr[2] + ka_, IMG, la_ + 2048);                                                    \
+        VDB_DMA_NT(aptr[3] + ka_, IMG, la_ + 3072);                                                    \
+        }                                                                                              \
+        if (!(p.ablate & 4u)) {                                                                        \
         VDB_DMA(bbase + (ob[0] + kb_), IMG, lb_);                                                      \
         VDB_DMA(bbase + (ob[1] + kb_), IMG, lb_ + 1024);                                               \
+        }                                                                                              \
     }
 
     // ---- row constants of a tile, one tile ahead, by LDS-DMA (4 bytes per lane): waves 0-3 fetch alpha and the mask
@@ -259,6 +265,7 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
         // ---- 2 k-steps of 16: fragments -> bf16 -> 8 MFMAs each
         const char* ap = img + a_row_off;
         const char* bp = img + b_row_off;
+        if (!(p.ablate & 1u))
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             bf16x8 fa[MT], fb[QT];
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
 
-        if (ks == KS - 1) {
+        if (ks == KS - 1 && !(p.ablate & 8u)) {
             const uint32_t par = tile & 1u;
             // (the constants of this tile were issued at least one counted top-of-stage wait + barrier ago: every
             // stage that issues them either issues 6 row/query pieces after them or is followed by a vmcnt(0) wait)
@@ -317,33 +324,47 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
                 for (int j = 0; j < 4; ++j) {
                     const float4 a4 = *reinterpret_cast<const float4*>(al + i * 32 + 8 * j);
                     const float4 b4 = *reinterpret_cast<const float4*>(be + i * 32 + 8 * j);
-#define VDB_ELEM(E, AC, BC)                                                                            \
+                    // scores of 4 rows x 2 queries
+                    const float sa0 = fmaf(acc[i][0][4 * j + 0], a4.x, b4.x), sa1 = fmaf(acc[i][0][4 * j + 1], a4.y, b4.y);
+                    const float sa2 = fmaf(acc[i][0][4 * j + 2], a4.z, b4.z), sa3 = fmaf(acc[i][0][4 * j + 3], a4.w, b4.w);
+                    const float sb0 = fmaf(acc[i][1][4 * j + 0], a4.x, b4.x), sb1 = fmaf(acc[i][1][4 * j + 1], a4.y, b4.y);
+                    const float sb2 = fmaf(acc[i][1][4 * j + 2], a4.z, b4.z), sb3 = fmaf(acc[i][1][4 * j + 3], a4.w, b4.w);
+                    const uint32_t rt0 = rowb + 8 * j;                  // tile-row of element 0
+                    if (SAMPLE) {
+                        // smallest (ordered score, tile-row) of the lane's eligible rows; a NaN score orders first (key 0)
+#define VDB_MIN(E, SA, SB)                                                                             \
     {                                                                                                  \
         const bool ok_ = (vbits >> (8 * j + (E))) & 1u;                                                \
-        const float sa_ = fmaf(acc[i][0][4 * j + (E)], (AC), (BC));                                    \
-        const float sb_ = fmaf(acc[i][1][4 * j + (E)], (AC), (BC));                                    \
-        if (SAMPLE) {                                                                                  \
-            /* smallest (ordered score, tile-row) of the lane's rows; a NaN score orders first (key 0) */      \
-            const uint32_t oa_ = (sa_ != sa_) ? 0u : f32_to_ordered(sa_);                              \
-            const uint32_t ob_ = (sb_ != sb_) ? 0u : f32_to_ordered(sb_);                              \
-            if (ok_ && oa_ < best_a) { best_a = oa_; brow_a = rowb + 8 * j + (E); }                    \
-            if (ok_ && ob_ < best_b) { best_b = ob_; brow_b = rowb + 8 * j + (E); }                    \
-        } else {                                                                                       \
-            if (!(sa_ > thr_a) && ok_) {                                                               \
-                if (pcnt_a < p.capl) pool_a[pcnt_a] = make_raw_key(sa_, tr0 + rowb + 8 * j + (E));     \
-                ++pcnt_a;                                                                              \
-            }                                                                                          \
-            if (!(sb_ > thr_b) && ok_) {                                                               \
-                if (pcnt_b < p.capl) pool_b[pcnt_b] = make_raw_key(sb_, tr0 + rowb + 8 * j + (E));     \
-                ++pcnt_b;                                                                              \
-            }                                                                                          \
-        }                                                                                              \
+        const uint32_t oa_ = ((SA) != (SA)) ? 0u : f32_to_ordered(SA);                                 \
+        const uint32_t ob_ = ((SB) != (SB)) ? 0u : f32_to_ordered(SB);                                 \
+        if (ok_ && oa_ < best_a) { best_a = oa_; brow_a = rt0 + (E); }                                 \
+        if (ok_ && ob_ < best_b) { best_b = ob_; brow_b = rt0 + (E); }                                 \
     }
-                    VDB_ELEM(0, a4.x, b4.x)
-                    VDB_ELEM(1, a4.y, b4.y)
-                    VDB_ELEM(2, a4.z, b4.z)
-                    VDB_ELEM(3, a4.w, b4.w)
-#undef VDB_ELEM
+                        VDB_MIN(0, sa0, sb0) VDB_MIN(1, sa1, sb1) VDB_MIN(2, sa2, sb2) VDB_MIN(3, sa3, sb3)
+#undef VDB_MIN
+                    } else {
+                        // Hits are rare (about 0.2 % of the elements).  Common path per query: four compares whose
+                        // lane masks are OR-ed on the scalar unit and ONE not-taken branch; the append code is out of
+                        // line.  `!(s > thr)` keeps a NaN score (it must reach the re-rank, flat_index.rs:62).
+                        const unsigned long long ma = __builtin_amdgcn_ballot_w64(!(sa0 > thr_a)) | __builtin_amdgcn_ballot_w64(!(sa1 > thr_a)) |
+                                                      __builtin_amdgcn_ballot_w64(!(sa2 > thr_a)) | __builtin_amdgcn_ballot_w64(!(sa3 > thr_a));
+                        const unsigned long long mb = __builtin_amdgcn_ballot_w64(!(sb0 > thr_b)) | __builtin_amdgcn_ballot_w64(!(sb1 > thr_b)) |
+                                                      __builtin_amdgcn_ballot_w64(!(sb2 > thr_b)) | __builtin_amdgcn_ballot_w64(!(sb3 > thr_b));
+#define VDB_PUSH(E, S, THR, POOL, PCNT)                                                                \
+    if (!((S) > (THR)) && ((vbits >> (8 * j + (E))) & 1u)) {                                           \
+        if (PCNT < p.capl) POOL[PCNT] = make_raw_key((S), tr0 + rt0 + (E));                            \
+        ++PCNT;                                                                                        \
+    }
+                        if (__builtin_expect(ma != 0ull, 0)) {
+                            VDB_PUSH(0, sa0, thr_a, pool_a, pcnt_a) VDB_PUSH(1, sa1, thr_a, pool_a, pcnt_a)
+                            VDB_PUSH(2, sa2, thr_a, pool_a, pcnt_a) VDB_PUSH(3, sa3, thr_a, pool_a, pcnt_a)
+                        }
+                        if (__builtin_expect(mb != 0ull, 0)) {
+                            VDB_PUSH(0, sb0, thr_b, pool_b, pcnt_b) VDB_PUSH(1, sb1, thr_b, pool_b, pcnt_b)
+                            VDB_PUSH(2, sb2, thr_b, pool_b, pcnt_b) VDB_PUSH(3, sb3, thr_b, pool_b, pcnt_b)
+                        }
+#undef VDB_PUSH
+                    }
                 }
             }
             if (SAMPLE) {
@@ -384,6 +405,7 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
         p.pool_cnt[sub_b] = pcnt_b;
     }
 #undef VDB_DMA
+#undef VDB_DMA_NT
 #undef VDB_DMA4
 #undef VDB_ISSUE
 }

@@ -380,7 +380,9 @@ Bf16Plan plan_bf16(uint32_t n, size_t k) {
     if (const char* e = getenv("VDB_SAMPLE16")) S = pow2_ceil(std::max(256, atoi(e)));
     while (S / 256u < want_kt && 2 * S <= n / 2) S *= 2;
     while (S > n) S /= 2;
-    uint32_t kt = std::min<uint32_t>(128u, (uint32_t)(S / 256u));
+    // threshold rank: enough for the first re-rank round; the pool (about N/S * kt keys) feeds the deeper rounds
+    uint32_t kt = std::min<uint32_t>(want_kt, (uint32_t)(S / 256u));
+    if (const char* e = getenv("VDB_KT16")) kt = std::min<uint32_t>((uint32_t)std::max(1, atoi(e)), (uint32_t)(S / 256u));
     if (kt < k + 1 || kt < 16) return pl;
     pl.kp = 256; pl.S = (uint32_t)S; pl.kt = kt;
     while ((1ull << pl.shift) < S) ++pl.shift;
@@ -558,6 +560,7 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w_qb.p + (size_t)q0 * ld;
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
         fp.thr = ix->w_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
+        fp.ablate = getenv("VDB_BF16_ABLATE") ? (uint32_t)atoi(getenv("VDB_BF16_ABLATE")) : 0u;
         fp.n_sample = S; fp.sample_shift = pl.shift; fp.minkeys = ix->w_dense.p; fp.minkey_stride = M;
         vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);
 
@@ -593,7 +596,7 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         rp.out_counts = d_out_counts + q0; rp.out_stride = (uint32_t)k; rp.cert = d_cert + q0; rp.status = d_status;
         rp.thr = ix->w_thr.p + q0;
         rp.qerr = ix->w_qerr.p + q0; rp.c_acc = c_acc_bf16(ix);
-        rp.kp_first = round_up((uint32_t)k + 22u, 32u); rp.kp_step = 32;
+        rp.kp_first = round_up((uint32_t)k + 38u, 16u); rp.kp_step = 32;
         vdb::launch_rerank(rp, nb, s);
     }
     return VDB_OK;
