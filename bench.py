@@ -158,19 +158,23 @@ def main():
     # launch = 4*N*d + 4*B*d.  The f32 MFMA tier (set_screen(0)) is measured beside it in the same
     # run: bound by the f32-input MFMA peak, algorithmic FLOPs 2*B*N*d.
     def kernel_ms_of(n_iter):
+        # average duration of ONE launch of the dominant kernel (a batch above 256 queries takes several passes, and
+        # the counter sums their launches; rows_scanned / shard rows = launches of that search)
         index.set_profile(True)
         ns = []
         for _ in range(n_iter):
             step()
-            ns.append(index.last_stats()["fused_kernel_ns"])
+            st_ = index.last_stats()
+            ns.append(st_["fused_kernel_ns"] / max(1, round(st_["rows_scanned"] / max(hi - lo, 1))))
         index.set_profile(False)
         return float(np.mean(ns)) / 1e6
 
     n_prof = max(3, min(args.steps, 10))
     kern_ms = kernel_ms_of(n_prof)
     local_rows = hi - lo
-    alg_flops = 2.0 * B * local_rows * dim                      # 2*B*N*d per launch
-    alg_bytes = 4.0 * local_rows * dim + 4.0 * B * dim
+    b_launch = min(B, 256)                                      # queries of one launch (a pass handles up to 256)
+    alg_flops = 2.0 * b_launch * local_rows * dim               # 2*B*N*d per launch
+    alg_bytes = 4.0 * local_rows * dim + 4.0 * b_launch * dim
     screened = bool(stats.get("bf16_screen"))
     traffic = None
     tp = os.path.join(ROOT, "profiles", "traffic.json")

@@ -176,6 +176,7 @@ int vdb_flat_last_stats(const vdb_flat_index *h, uint64_t out[8]);
 /* The same counters followed by (n up to 16, the rest reads 0):
  *  [8] 1 when the bf16 screening tier answered the batch first, 0 when only the f32 MFMA tier ran
  *  [9] queries the screening tier could not certify and handed to the f32 MFMA tier
+ *  [10] [11] [12] host clock of the call, ns: first tier enqueued / its flags on the host / return
  * With the screening tier on, [4] [5] [7] describe ITS sample, k' and kernel time. */
 int vdb_flat_last_stats_ex(const vdb_flat_index *h, uint64_t *out, size_t n);
 

@@ -27,9 +27,15 @@ out["_notes"] = {"kernel": name, "workload": "bench.py default: 1Mx768 f32 cosin
     "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request for 16-B/lane streaming reads (MI355X_MICROARCH.md, HBM section); calibrated in round 1 on the 384 MB device-to-device copy of bench.py's index build (WRITE_SIZE 366.2 MiB exact, FETCH_SIZE 183.1 MiB = 1/2)",
     "hbm_bytes_per_launch": 2 * fetch + write, "algorithmic_bytes": 3072786432}
 json.dump(out, open(os.path.join(root, f"profiles/{tag}_pmc_fused.json"), "w"), indent=1)
-json.dump({"hbm_bytes_per_launch": 2 * fetch + write, "fetch_size_raw_bytes": fetch, "write_size_bytes": write,
-           "source": f"profiles/{tag}_pmc_fused.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled per the gfx950 correction)",
-           "workload": "bench.py default (1Mx768 f32, batch 256, k=10, 1 GPU)"}, open(os.path.join(root, "profiles/traffic.json"), "w"), indent=1)
+tpath = os.path.join(root, "profiles/traffic.json")
+tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+screened = "bf16" in (name or "")
+key = "hbm_bytes_per_launch_bf16_screen" if screened else "hbm_bytes_per_launch"
+tj[key] = 2 * fetch + write
+tj[key + "_detail"] = {"fetch_size_raw_bytes": fetch, "write_size_bytes": write, "kernel": name,
+    "source": f"profiles/{tag}_pmc_fused.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled per the gfx950 correction)"}
+tj["workload"] = "bench.py default (1Mx768 f32, batch 256, k=10, 1 GPU)"
+json.dump(tj, open(tpath, "w"), indent=1)
 bench = open(os.path.join(root, "gpurun_out/bench_final.json")).read().strip().splitlines()[-1]
 open(os.path.join(root, f"profiles/{tag}_bench_line.json"), "w").write(bench + "\n")
 print(json.dumps({k: v for k, v in out.items() if k != "_notes"}, indent=1)[:1800]); print(out["_notes"]["hbm_bytes_per_launch"])

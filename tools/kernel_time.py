@@ -23,8 +23,11 @@ ids = torch.empty((B, k), dtype=torch.int64, device=dev); ds = torch.empty((B, k
 def step(): ix.search_batch_device(q.data_ptr(), B, dim, k, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr())
 for _ in range(3): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(20): step()
+hs = []
+for _ in range(20):
+    step(); st_ = ix.last_stats(); hs.append((st_["host_enqueued_ns"], st_["host_flags_ns"], st_["host_total_ns"]))
 torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 50
+print("host us (enqueued, flags on host, total):", np.mean(hs, axis=0) / 1e3)
 ix.set_profile(True); ks = []
 for _ in range(10): step(); ks.append(ix.last_stats()["fused_kernel_ns"] / 1e6)
 st = ix.last_stats()

@@ -572,6 +572,8 @@ __device__ __forceinline__ bool cert_test(const RerankParams& p, uint32_t q, flo
     return ek * ek < (double)T + qn * qn - eps * (s * s + ek * ek);
 }
 
+typedef __attribute__((address_space(3))) void* rr_lds_t;
+typedef const __attribute__((address_space(1))) void* rr_glb_t;
 constexpr uint32_t RR_MAX = 256;        // candidates per query at most
 constexpr uint32_t RR_THREADS = 512;
 
@@ -620,30 +622,14 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
         // ---- exact distances of candidates [processed, target)
         for (uint32_t c0 = processed; c0 < target; c0 += chunk) {
             const uint32_t nthis = (target - c0 < chunk) ? target - c0 : chunk;
-            // stage: wave wv copies rows wv, wv+8, ... of the chunk; 8 independent 16-byte loads in flight per lane
-            const uint32_t rows_w = nthis > wv ? (nthis - wv + nwaves - 1) / nwaves : 0;
-            const uint32_t units = rows_w * bpr;
-            for (uint32_t u0 = 0; u0 < units; u0 += 8) {
-                float4 v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t u = u0 + j;
-                    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (u < units) {
-                        const uint32_t r = wv + (u / bpr) * nwaves, c4 = (u % bpr) * 64 + lane;
-                        const uint32_t row = sRowIdx[c0 + r];
-                        if (c4 < vpr && row != 0xffffffffu)
-                            v[j] = *reinterpret_cast<const float4*>(p.rows + (size_t)row * p.ld + 4 * c4);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const uint32_t u = u0 + j;
-                    if (u < units) {
-                        const uint32_t r = wv + (u / bpr) * nwaves, c4 = (u % bpr) * 64 + lane;
-                        if (c4 < vpr) *reinterpret_cast<float4*>(sR + (size_t)r * ldp + 4 * c4) = v[j];
-                    }
-                }
+            // stage the chunk's rows by LDS-DMA (global_load_lds_dwordx4: 1 KB of a row per wave instruction, no VGPR
+            // round trip), every piece of the chunk in flight at once; the barrier's vmcnt(0) waits for them
+            for (uint32_t u = wv; u < nthis * bpr; u += nwaves) {
+                const uint32_t r = u / bpr, b = u % bpr, c4 = b * 64 + lane;
+                const uint32_t row = sRowIdx[c0 + r];
+                if (row != 0xffffffffu && c4 < vpr)
+                    __builtin_amdgcn_global_load_lds((rr_glb_t)(p.rows + (size_t)row * p.ld + 4 * c4),
+                                                     (rr_lds_t)(sR + (size_t)r * ldp + 256 * b), 16, 0, 0);
             }
             __syncthreads();
             if (tid < nthis) {

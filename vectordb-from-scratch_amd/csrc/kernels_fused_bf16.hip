@@ -80,20 +80,26 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
     const uint32_t KS = ld / KSTAGE;
 
     // ---- the rows this workgroup covers
-    uint32_t r0 = 0, r1 = 0, ntiles = 0, tile_first = 0, tile_step = 1;
+    // (sample mode: exactly ONE tile per workgroup, grid = number of sample tiles.  A compile-time tile count lets
+    // the compiler drop the next-tile address state; with it the sample instance spilled registers to scratch, and
+    // every scratch reload put a vmcnt(0) -- a full drain of the DMA pipeline -- into the stage loop)
+    uint32_t r0 = 0, r1 = 0, ntiles_rt = 0;
+    const uint32_t tile_first = SAMPLE ? blockIdx.x : 0u;
+    constexpr uint32_t tile_step = 0;
     if (SAMPLE) {
-        const uint32_t stiles = (p.n_sample + TR - 1) / TR;
-        tile_first = blockIdx.x;
-        tile_step = gridDim.x;
-        ntiles = tile_first < stiles ? (stiles - tile_first + tile_step - 1) / tile_step : 0;
+        ntiles_rt = 1;
     } else {
-        const uint32_t nblk = (p.n_rows + 31) >> 5;
+        // row ranges in WHOLE tiles: a range of 15.26 tiles costs 16 tile iterations whatever its last tile holds, so
+        // the tiles are dealt out whole -- some workgroups run one tile fewer, and the last tiles of the others meet
+        // an HBM that is no longer contended
+        const uint32_t nblk = (p.n_rows + TR - 1) / TR;
         const uint32_t b0 = (uint32_t)(((uint64_t)blockIdx.x * nblk) / p.n_wg);
         const uint32_t b1 = (uint32_t)(((uint64_t)(blockIdx.x + 1) * nblk) / p.n_wg);
-        r0 = b0 * 32;
-        r1 = (b1 * 32 < p.n_rows) ? b1 * 32 : p.n_rows;
-        ntiles = r0 < r1 ? (r1 - r0 + TR - 1) / TR : 0;
+        r0 = b0 * TR;
+        r1 = (b1 * TR < p.n_rows) ? b1 * TR : p.n_rows;
+        ntiles_rt = r0 < r1 ? (r1 - r0 + TR - 1) / TR : 0;
     }
+    const uint32_t ntiles = SAMPLE ? 1u : ntiles_rt;
     // queries of this lane: one column in each of the wave's two 32-query MFMA tiles
     const uint32_t q_a = wq * 64 + c, q_b = q_a + 32;
     uint64_t* pool_a = nullptr; uint64_t* pool_b = nullptr;
@@ -117,6 +123,12 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
     }
     const uint32_t total = ntiles * KS;
     const uint32_t last_row = p.n_rows - 1;
+    // sample index -> device row.  Scattered: (j * n) >> shift.  Block mode (sample_block != 0): the sample is made of
+    // 256-row tiles of CONTIGUOUS rows spaced sample_block rows apart, i.e. the access pattern of the filter pass.
+    auto sample_row_of = [&](uint32_t j) -> uint32_t {
+        if (p.sample_block) return (j >> 8) * p.sample_block + (j & 255u);
+        return (uint32_t)(((uint64_t)j * p.n_rows) >> p.sample_shift);
+    };
     const char* __restrict__ rows_b = reinterpret_cast<const char*>(p.rows);
     const char* __restrict__ bbase = reinterpret_cast<const char*>(p.qb);
 
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
         if (SAMPLE) {
             uint32_t j = (tile_first + t * tile_step) * TR + rt;
             if (j >= p.n_sample) j = p.n_sample - 1;
-            return (uint32_t)(((uint64_t)j * p.n_rows) >> p.sample_shift);      // n_sample = 2^sample_shift <= n_rows
+            return sample_row_of(j);                                   // n_sample = 2^sample_shift <= n_rows
         } else {
             const uint32_t r = r0 + t * TR + rt;
             return r > last_row ? last_row : r;
@@ -305,7 +317,7 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
                 if (SAMPLE) {
                     const uint32_t sj = sj0 + rt;
                     in = sj < p.n_sample;
-                    const uint32_t row = (uint32_t)(((uint64_t)sj * p.n_rows) >> p.sample_shift);
+                    const uint32_t row = sample_row_of(sj);
                     bit = row & 31;
                 } else {
                     in = tr0 + rt < r1;
@@ -313,7 +325,7 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
                 }
                 val[m] = __ballot(in && ((sMaskW[par * TR + rt] >> bit) & 1u));
             }
-            uint32_t best_a = 0xffffffffu, best_b = 0xffffffffu, brow_a = 0xffffffffu, brow_b = 0xffffffffu;
+            float best_a = __uint_as_float(0x7f800000u), best_b = best_a;   // sample mode: running group minima
             const float* al = sAlpha + par * TR + wr * 128 + 4 * h;
             const float* be = sBeta + par * TR + wr * 128 + 4 * h;
 #pragma unroll
@@ -331,14 +343,14 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
                     const float sb2 = fmaf(acc[i][1][4 * j + 2], a4.z, b4.z), sb3 = fmaf(acc[i][1][4 * j + 3], a4.w, b4.w);
                     const uint32_t rt0 = rowb + 8 * j;                  // tile-row of element 0
                     if (SAMPLE) {
-                        // smallest (ordered score, tile-row) of the lane's eligible rows; a NaN score orders first (key 0)
+                        // smallest score of the lane's eligible rows (v_min_f32 skips a NaN score: such a row is no witness
+                        // for a threshold, and it reaches the re-rank through the filter pass, which keeps NaN scores)
+                        const float inf_ = __uint_as_float(0x7f800000u);
 #define VDB_MIN(E, SA, SB)                                                                             \
     {                                                                                                  \
         const bool ok_ = (vbits >> (8 * j + (E))) & 1u;                                                \
-        const uint32_t oa_ = ((SA) != (SA)) ? 0u : f32_to_ordered(SA);                                 \
-        const uint32_t ob_ = ((SB) != (SB)) ? 0u : f32_to_ordered(SB);                                 \
-        if (ok_ && oa_ < best_a) { best_a = oa_; brow_a = rt0 + (E); }                                 \
-        if (ok_ && ob_ < best_b) { best_b = ob_; brow_b = rt0 + (E); }                                 \
+        best_a = fminf(best_a, ok_ ? (SA) : inf_);                                                     \
+        best_b = fminf(best_b, ok_ ? (SB) : inf_);                                                     \
     }
                         VDB_MIN(0, sa0, sb0) VDB_MIN(1, sa1, sb1) VDB_MIN(2, sa2, sb2) VDB_MIN(3, sa3, sb3)
 #undef VDB_MIN
@@ -370,10 +382,9 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
             if (SAMPLE) {
                 // one group minimum per (tile, row half, lane half) and query
                 const uint32_t g = (((tile_first + tile * tile_step) * 2 + wr) * 2 + h);
-                const uint32_t ra_ = brow_a == 0xffffffffu ? 0u : (uint32_t)(((uint64_t)(sj0 + brow_a) * p.n_rows) >> p.sample_shift);
-                const uint32_t rb_ = brow_b == 0xffffffffu ? 0u : (uint32_t)(((uint64_t)(sj0 + brow_b) * p.n_rows) >> p.sample_shift);
-                p.minkeys[(size_t)q_a * p.minkey_stride + g] = brow_a == 0xffffffffu ? EMPTY_KEY : (((uint64_t)best_a << 32) | ra_);
-                p.minkeys[(size_t)q_b * p.minkey_stride + g] = brow_b == 0xffffffffu ? EMPTY_KEY : (((uint64_t)best_b << 32) | rb_);
+                // the key's low word only has to make the keys of one query distinct: the group index
+                p.minkeys[(size_t)q_a * p.minkey_stride + g] = best_a < __uint_as_float(0x7f800000u) ? make_key(best_a, g) : EMPTY_KEY;
+                p.minkeys[(size_t)q_b * p.minkey_stride + g] = best_b < __uint_as_float(0x7f800000u) ? make_key(best_b, g) : EMPTY_KEY;
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -420,7 +431,8 @@ void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s) {
 void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s) {
     const uint32_t stiles = (p.n_sample + TR - 1) / TR;
     if (!stiles) return;
-    hipLaunchKernelGGL(fused_bf16_kernel<true>, dim3(stiles < n_cu ? stiles : n_cu), dim3(NT), 0, s, p);
+    (void)n_cu;
+    hipLaunchKernelGGL(fused_bf16_kernel<true>, dim3(stiles), dim3(NT), 0, s, p);
 }
 
 }  // namespace vdb

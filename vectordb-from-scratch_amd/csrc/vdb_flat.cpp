@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -543,7 +544,7 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
     const uint32_t S = pl.S, kp = pl.kp, KT = pl.kt;
     const uint32_t M = vdb::fused_bf16_sample_groups(S);
     const uint32_t capl = 64;
-    const uint32_t n_wg = std::min<uint32_t>((uint32_t)ix->n_cu, (n + 31) / 32);
+    const uint32_t n_wg = std::min<uint32_t>((uint32_t)ix->n_cu, (n + vdb::fused_bf16_tile_rows() - 1) / vdb::fused_bf16_tile_rows());
     const uint32_t n_sub = vdb::fused_bf16_subpools_per_query(n_wg);
     if ((rc = ix->w_dense.ensure((size_t)SUPER * M))) return rc;
     if ((rc = ix->w_cand.ensure((size_t)SUPER * kp))) return rc;
@@ -561,7 +562,8 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
         fp.thr = ix->w_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
         fp.ablate = getenv("VDB_BF16_ABLATE") ? (uint32_t)atoi(getenv("VDB_BF16_ABLATE")) : 0u;
-        fp.n_sample = S; fp.sample_shift = pl.shift; fp.minkeys = ix->w_dense.p; fp.minkey_stride = M;
+        fp.n_sample = S; fp.sample_shift = pl.shift;
+        fp.sample_block = getenv("VDB_SAMPLE_BLOCK") ? (n / (S / 256u)) : 0u; fp.minkeys = ix->w_dense.p; fp.minkey_stride = M;
         vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);
 
         vdb::SelectParams sp{};
@@ -614,6 +616,8 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
     // events bracket them); the workspace is protected by the handle mutex and the final sync
     hipStream_t s = user_stream ? user_stream : ix->stream;
     memset(ix->stats, 0, sizeof(ix->stats));
+    const auto t_entry = std::chrono::steady_clock::now();
+    auto since = [&]() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_entry).count(); };
     size_t total_rows = ix->n_live + ix->misfits.size();
     if (total_rows == 0 || k == 0) {   // storage.rs:218-220: empty store -> Ok(vec![]) before any check
         HIP_TRY(hipMemsetAsync(d_out_counts, 0, nq * 4, s));
@@ -716,7 +720,9 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, (4 + 2 * (size_t)nq32) * 4, hipMemcpyDeviceToHost, s));
+    ix->stats[10] = since();                       // host time until everything of the first tier is enqueued, ns
     HIP_TRY(hipStreamSynchronize(s));
+    ix->stats[11] = since();                       // ... until the first tier's flags are on the host, ns
     uint32_t status = ix->h_flags[0];
     if (status & vdb::ST_ZERO_QUERY)
         return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
@@ -816,6 +822,7 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
                                 d_out_counts + q)))
                 return rc;
     }
+    ix->stats[12] = since();                       // whole call, ns
     ix->stats[0] = nq32 - n_fallback;
     ix->stats[1] = n_fallback;
     uint32_t st2 = status;
