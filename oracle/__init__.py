@@ -21,8 +21,8 @@ _lib = None
 
 def build(force=False):
     """Compile liboracle.so with the recipe in oracle/Makefile."""
-    src = os.path.join(_HERE, "flat_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("flat_oracle.c", "hnsw_oracle.c", "Makefile")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -148,3 +148,108 @@ def recall(truth_ids, found_ids):
     t = np.ascontiguousarray(truth_ids, dtype=np.uint64)
     f = np.ascontiguousarray(found_ids, dtype=np.uint64)
     return float(lib().vdbo_recall(_u64p(t), t.size, _u64p(f), f.size))
+
+
+# ---------------------------------------------------------------------------------------------
+# HNSW oracle (oracle/hnsw_oracle.c): restatement of src/hnsw/{graph,neighbor_queue,mod}.rs
+# ---------------------------------------------------------------------------------------------
+_hnsw_bound = False
+
+
+def _hnsw_lib():
+    global _hnsw_bound
+    L = lib()
+    if not _hnsw_bound:
+        c = ctypes
+        vp, sz, u64, fp, u64p, szp = c.c_void_p, c.c_size_t, c.c_uint64, c.POINTER(c.c_float), c.POINTER(c.c_uint64), c.POINTER(c.c_size_t)
+        L.vdbo_hnsw_create.restype = vp
+        L.vdbo_hnsw_create.argtypes = [c.c_int, sz, sz, sz, u64]
+        L.vdbo_hnsw_destroy.argtypes = [vp]
+        L.vdbo_hnsw_destroy.restype = None
+        L.vdbo_hnsw_len.restype = sz
+        L.vdbo_hnsw_len.argtypes = [vp]
+        L.vdbo_hnsw_distance_evals.restype = u64
+        L.vdbo_hnsw_distance_evals.argtypes = [vp]
+        L.vdbo_hnsw_entry_point.argtypes = [vp, u64p, szp]
+        L.vdbo_hnsw_neighbors.restype = c.c_long
+        L.vdbo_hnsw_neighbors.argtypes = [vp, u64, sz, u64p, sz]
+        L.vdbo_hnsw_node_level.restype = c.c_long
+        L.vdbo_hnsw_node_level.argtypes = [vp, u64]
+        L.vdbo_hnsw_insert.argtypes = [vp, u64, fp, sz, c.c_long]
+        L.vdbo_hnsw_remove.argtypes = [vp, u64]
+        L.vdbo_hnsw_search.argtypes = [vp, fp, sz, sz, sz, u64p, fp, szp]
+        L.vdbo_hnsw_level_from_unit.restype = sz
+        L.vdbo_hnsw_level_from_unit.argtypes = [c.c_double, c.c_double, sz]
+        L.vdbo_heap_replay.argtypes = [c.c_int, fp, u64p, sz, sz, fp, u64p, szp]
+        L.vdbo_heap_replay.restype = None
+        _hnsw_bound = True
+    return L
+
+
+class HnswOracle:
+    """HnswGraph / HnswIndex of the reference on the CPU.  Levels come from a seeded stream (the reference's
+    StdRng::from_entropy() is not reproducible); everything else follows graph.rs operation by operation."""
+
+    def __init__(self, metric, m=16, ef_construction=200, ef_search=50, seed=1):
+        self._L = _hnsw_lib()
+        self._h = ctypes.c_void_p(self._L.vdbo_hnsw_create(int(metric), m, ef_construction, ef_search, seed))
+        self.ef_search = ef_search
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.vdbo_hnsw_destroy(self._h)
+            self._h = None
+
+    def __len__(self):
+        return int(self._L.vdbo_hnsw_len(self._h))
+
+    def insert(self, id_, vec, level=-1):
+        v = _f32(vec)
+        rc = self._L.vdbo_hnsw_insert(self._h, int(id_), _fp(v), v.size, int(level))
+        if rc:
+            raise OracleError(rc)
+
+    def remove(self, id_):
+        self._L.vdbo_hnsw_remove(self._h, int(id_))
+
+    def search(self, query, k, ef=None):
+        """search_knn(query, k, ef) (graph.rs:386-412); HnswIndex::search uses ef = 50 (mod.rs:71)."""
+        q = _f32(query)
+        ids = np.zeros(max(int(k), 1), dtype=np.uint64)
+        ds = np.zeros(ids.size, dtype=np.float32)
+        cnt = ctypes.c_size_t()
+        rc = self._L.vdbo_hnsw_search(self._h, _fp(q), q.size, int(k), int(self.ef_search if ef is None else ef),
+                                      _u64p(ids), _fp(ds), ctypes.byref(cnt))
+        if rc:
+            raise OracleError(rc)
+        return ids[:cnt.value].copy(), ds[:cnt.value].copy()
+
+    def entry_point(self):
+        ep, ml = ctypes.c_uint64(), ctypes.c_size_t()
+        has = self._L.vdbo_hnsw_entry_point(self._h, ctypes.byref(ep), ctypes.byref(ml))
+        return (int(ep.value), int(ml.value)) if has else (None, 0)
+
+    def level(self, id_):
+        return int(self._L.vdbo_hnsw_node_level(self._h, int(id_)))
+
+    def neighbors(self, id_, layer):
+        buf = np.zeros(256, dtype=np.uint64)
+        n = self._L.vdbo_hnsw_neighbors(self._h, int(id_), int(layer), _u64p(buf), buf.size)
+        return None if n < 0 else [int(x) for x in buf[:n]]
+
+    def distance_evals(self):
+        return int(self._L.vdbo_hnsw_distance_evals(self._h))
+
+
+def heap_replay(sign, dists, ids, bound=0):
+    """push all (pop the top whenever the size exceeds `bound`), then pop all: Rust BinaryHeap order."""
+    L = _hnsw_lib()
+    d, i = _f32(dists), np.ascontiguousarray(ids, dtype=np.uint64)
+    od, oi, n = np.zeros(d.size, np.float32), np.zeros(d.size, np.uint64), ctypes.c_size_t()
+    L.vdbo_heap_replay(int(sign), _fp(d), _u64p(i), d.size, int(bound), _fp(od), _u64p(oi), ctypes.byref(n))
+    return od[:n.value].copy(), oi[:n.value].copy()
+
+
+def hnsw_level_from_unit(r, m=16, max_layers=16):
+    import math
+    return int(_hnsw_lib().vdbo_hnsw_level_from_unit(float(r), 1.0 / math.log(m), max_layers))
