@@ -14,12 +14,15 @@ def test_library_builds_and_exports_every_declared_symbol():
     path = vdb.build()
     assert os.path.exists(path)
     L = ctypes.CDLL(path)
-    header = open(os.path.join(ROOT, "include", "vdb_flat.h")).read()
-    declared = set(re.findall(r"\b(vdb_[a-z0-9_]+)\s*\(", header))
+    declared = set()
+    for h in ("vdb_flat.h", "vdb_hnsw.h"):
+        header = open(os.path.join(ROOT, "include", h)).read()
+        header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)            # declarations only, not the prose
+        declared |= set(re.findall(r"\b(vdb_[a-z0-9_]+)\s*\(", header))
     declared -= {"vdb_status", "vdb_metric"}
     assert declared, "no declarations parsed"
     for name in sorted(declared):
-        assert hasattr(L, name), f"{name} declared in include/vdb_flat.h but not exported"
+        assert hasattr(L, name), f"{name} declared in include/*.h but not exported"
     assert set(vdb._ffi.SYMBOLS) == declared
     assert L.vdb_abi_version() == 1
     L.vdb_build_arch.restype = ctypes.c_char_p
@@ -29,6 +32,9 @@ def test_library_builds_and_exports_every_declared_symbol():
 def test_header_cites_reference_lines():
     header = open(os.path.join(ROOT, "include", "vdb_flat.h")).read()
     for cite in ["src/index.rs", "src/flat_index.rs", "src/storage.rs", "src/distance.rs", "src/error.rs"]:
+        assert cite in header
+    header = open(os.path.join(ROOT, "include", "vdb_hnsw.h")).read()
+    for cite in ["src/hnsw/mod.rs", "src/hnsw/graph.rs", "neighbor_queue.rs", "src/index.rs"]:
         assert cite in header
 
 
@@ -48,7 +54,7 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="replace").read()
-                assert "import oracle" not in text and "liboracle" not in text and "flat_oracle" not in text, f
+                assert "import oracle" not in text and "liboracle" not in text and "flat_oracle" not in text and "hnsw_oracle" not in text, f
 
 
 def test_metadata_filter_semantics():

@@ -1,0 +1,170 @@
+"""The GPU-offloaded HNSW index (include/vdb_hnsw.h, BASELINE config 5) against the CPU restatement of the
+reference's HNSW (oracle/hnsw_oracle.c).  With the same seed and insertion order the two must hold the SAME graph
+(entry point, node levels, every neighbour list in order) and return the SAME results (ids, order, distance bits):
+the product runs the reference's traversal and only moves the distance evaluations to the GPU.  Against the
+reference itself parity is statistical (its levels are unseeded): the recall floors of tests/recall_test.rs."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import load_package
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vdb():
+    v = load_package()
+    v.build()
+    return v
+
+
+def build_pair(vdb, metric, rows, m, efc, efs, seed, bulk=True, ids=None):
+    g = vdb.GpuHnswIndex(vdb.DistanceMetric(metric), vdb.HnswParams.new(m, efc, efs), seed=seed)
+    o = oracle.HnswOracle(metric, m=m, ef_construction=efc, ef_search=efs, seed=seed)
+    ids = np.arange(rows.shape[0], dtype=np.uint64) if ids is None else np.asarray(ids, dtype=np.uint64)
+    if bulk:
+        g.build_batch((ids, rows))
+    else:
+        for i, v in zip(ids, rows):
+            g.add(int(i), vdb.Vector(v))
+    for i, v in zip(ids, rows):
+        o.insert(int(i), v)
+    return g, o, ids
+
+
+def assert_same_graph(g, o, ids):
+    assert g.len() == len(o)
+    assert g.entry_point() == o.entry_point()
+    for i in ids:
+        lv = o.level(int(i))
+        assert g.level(int(i)) == lv, i
+        if lv < 0:
+            continue
+        for l in range(lv + 1):
+            assert g.neighbors(int(i), l) == o.neighbors(int(i), l), (int(i), l)
+        assert g.neighbors(int(i), lv + 1) is None
+
+
+def assert_same_results(g, o, queries, k, ef):
+    gi, gd, gc = g.search_batch_arrays(queries, k, ef)
+    for b in range(queries.shape[0]):
+        oi, od = o.search(queries[b], k, ef)
+        assert gc[b] == len(oi), (b, gc[b], len(oi))
+        assert np.array_equal(gi[b, :gc[b]], oi), (b, gi[b, :gc[b]], oi)
+        assert np.array_equal(gd[b, :gc[b]].view(np.uint32), od.view(np.uint32)), (b, gd[b, :gc[b]], od)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("n,d,m,efc", [(300, 8, 4, 32), (1500, 48, 16, 200), (800, 100, 8, 64)])
+def test_graph_and_results_equal_the_cpu_restatement(vdb, metric, n, d, m, efc):
+    rng = np.random.default_rng(n + d + metric)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    queries = rng.standard_normal((37, d)).astype(np.float32)
+    g, o, ids = build_pair(vdb, metric, rows, m, efc, 50, seed=7 + metric)
+    assert_same_graph(g, o, ids)
+    assert_same_results(g, o, queries, 10, 100)
+    assert_same_results(g, o, queries[:5], 1, 16)
+    assert_same_results(g, o, queries[:5], 200, 50)                     # k > ef: ef_actual = k (graph.rs:406)
+    st = g.stats()
+    assert st["gpu_distances"] > 0 and st["last_search_rounds"] > 0
+
+
+def test_single_adds_equal_bulk_build(vdb):
+    rng = np.random.default_rng(5)
+    rows = rng.random((400, 12), dtype=np.float32)
+    a, o, ids = build_pair(vdb, 0, rows, 8, 64, 50, seed=3, bulk=False)
+    b, _, _ = build_pair(vdb, 0, rows, 8, 64, 50, seed=3, bulk=True)
+    assert_same_graph(a, o, ids)
+    assert_same_graph(b, o, ids)
+
+
+def test_duplicate_rows_tie_order_follows_the_heap_layout(vdb):
+    """Equal distances: into_sorted_vec keeps the BinaryHeap's array order among ties (neighbor_queue.rs:102-106);
+    the product and the restatement must agree on it."""
+    rng = np.random.default_rng(6)
+    base = rng.random((60, 6), dtype=np.float32)
+    rows = np.concatenate([base] * 5, 0)                                   # every vector 5 times
+    g, o, ids = build_pair(vdb, 0, rows, 6, 40, 50, seed=9)
+    assert_same_graph(g, o, ids)
+    assert_same_results(g, o, base[:20], 12, 64)
+
+
+def test_remove_semantics(vdb):
+    rng = np.random.default_rng(8)
+    rows = rng.random((500, 10), dtype=np.float32)
+    g, o, ids = build_pair(vdb, 0, rows, 8, 64, 50, seed=4)
+    ep, _ = o.entry_point()
+    for victim in [3, 77, 78, ep, 499, 12345]:                             # incl. the entry point and an absent id
+        g.remove(victim)
+        o.remove(victim)
+    assert_same_graph(g, o, ids)
+    q = rng.random((9, 10), dtype=np.float32)
+    assert_same_results(g, o, q, 10, 50)
+    # inserts after deletions keep following the same random stream
+    extra = rng.random((40, 10), dtype=np.float32)
+    for j, v in enumerate(extra):
+        g.add(1000 + j, vdb.Vector(v))
+        o.insert(1000 + j, v)
+    assert_same_graph(g, o, list(ids) + list(range(1000, 1040)))
+    assert_same_results(g, o, q, 10, 50)
+
+
+def test_reference_unit_tests_through_the_trait(vdb):
+    V, M = vdb.Vector, vdb.DistanceMetric
+    ix = vdb.GpuHnswIndex(M.Euclidean)                                     # mod.rs:88-98
+    ix.add(0, V([1.0, 0.0, 0.0])); ix.add(1, V([0.0, 1.0, 0.0])); ix.add(2, V([1.0, 1.0, 0.0]))
+    res = ix.search(V([1.0, 0.0, 0.0]), 2)
+    assert len(res) == 2 and res[0][0] == 0 and res[0][1] < 1e-5
+    assert ix.get_vector(0) == V([1.0, 0.0, 0.0]) and ix.get_vector(99) is None       # mod.rs:101-108
+    g = vdb.GpuHnswIndex(M.Euclidean, vdb.HnswParams.new(4, 32, 16))       # graph.rs:488-504
+    for i in range(5):
+        g.add(i, V([float(i), 0.0]))
+    r = g.search_with_ef(V([0.5, 0.0]), 2, 16)
+    assert len(r) == 2 and {r[0][0], r[1][0]} == {0, 1}
+    g = vdb.GpuHnswIndex(M.Euclidean, vdb.HnswParams.new(4, 32, 16))       # graph.rs:507-537
+    g.add(0, V([1.0, 0.0])); g.add(1, V([0.0, 1.0])); g.add(2, V([1.0, 1.0]))
+    ep, _ = g.entry_point()
+    g.remove(ep)
+    assert g.len() == 2 and len(g.search_with_ef(V([0.0, 1.0]), 1, 16)) == 1
+    assert vdb.GpuHnswIndex(M.Cosine).search(V([1.0, 2.0]), 3) == []       # empty graph (graph.rs:392-395)
+
+
+def test_hnsw_behind_the_vector_store(vdb):
+    # mod.rs:111-133 / :136-153: VectorStore::with_index(HnswIndex)
+    V = vdb.Vector
+    store = vdb.VectorStore.with_index(vdb.GpuHnswIndex(vdb.DistanceMetric.Euclidean, vdb.HnswParams.new(4, 32, 16)))
+    store.insert("v1", V([1.0, 0.0, 0.0])); store.insert("v2", V([0.0, 1.0, 0.0])); store.insert("v3", V([0.0, 0.0, 1.0]))
+    res = store.search(V([1.0, 0.1, 0.0]), 2)
+    assert len(res) == 2 and res[0].id == "v1"
+    store.delete("v1")
+    assert len(store) == 2
+
+
+def test_error_semantics(vdb):
+    V = vdb.Vector
+    ix = vdb.GpuHnswIndex(vdb.DistanceMetric.Cosine, vdb.HnswParams.new(4, 32, 16))
+    ix.add(0, V([1.0, 0.0])); ix.add(1, V([0.0, 1.0]))
+    with pytest.raises(vdb.InvalidVector):                                 # zero-norm query (distance.rs:51-55)
+        ix.search(V([0.0, 0.0]), 1)
+    with pytest.raises(vdb.DimensionMismatch):
+        ix.search(V([1.0, 0.0, 0.0]), 1)
+    with pytest.raises(vdb.DimensionMismatch):
+        ix.add(2, V([1.0, 0.0, 0.0]))
+
+
+@pytest.mark.parametrize("n,dim,nq,floor", [(100, 32, 50, 0.90), (1000, 64, 50, 0.90), (5000, 128, 20, 0.85)])
+def test_recall_floors_of_the_reference(vdb, n, dim, nq, floor):
+    # tests/recall_test.rs:28-80 with the GPU FlatIndex as ground truth
+    rng = np.random.default_rng(n)
+    rows = rng.random((n, dim), dtype=np.float32)
+    queries = rng.random((nq, dim), dtype=np.float32)
+    flat = vdb.GpuFlatIndex(vdb.DistanceMetric.Euclidean, keep_host_copy=False)
+    flat.add_bulk(rows)
+    hnsw = vdb.GpuHnswIndex(vdb.DistanceMetric.Euclidean, vdb.HnswParams.new(16, 200, 50), seed=n)
+    hnsw.build_batch((np.arange(n, dtype=np.uint64), rows))
+    ti, _, _ = flat.search_batch_arrays(queries, 10)
+    hi, hd, hc = hnsw.search_batch_arrays(queries, 10, 100)
+    rec = np.mean([len(set(ti[b]) & set(hi[b, :hc[b]])) / 10.0 for b in range(nq)])
+    assert rec >= floor, rec
+    assert np.all(hd[:, 1:] >= hd[:, :-1])

@@ -15,6 +15,10 @@ SYMBOLS = [
     "vdb_flat_reserve", "vdb_flat_flush", "vdb_flat_search", "vdb_flat_search_batch",
     "vdb_flat_search_batch_device", "vdb_flat_distances_batch", "vdb_merge_topk_device", "vdb_merge_topk_packed_device", "vdb_flat_set_profile", "vdb_flat_last_stats", "vdb_flat_last_stats_ex", "vdb_flat_set_screen", "vdb_last_error",
     "vdb_abi_version", "vdb_build_arch",
+    # include/vdb_hnsw.h
+    "vdb_hnsw_create", "vdb_hnsw_destroy", "vdb_hnsw_add", "vdb_hnsw_add_bulk", "vdb_hnsw_remove", "vdb_hnsw_search_batch",
+    "vdb_hnsw_len", "vdb_hnsw_metric", "vdb_hnsw_get_vector", "vdb_hnsw_neighbors", "vdb_hnsw_node_level",
+    "vdb_hnsw_entry_point", "vdb_hnsw_stats",
 ]
 
 _lib = None
@@ -60,6 +64,23 @@ def lib():
     L.vdb_flat_set_profile.argtypes = [vp, c.c_int]
     L.vdb_last_error.argtypes = [c.c_char_p, sz, szp, szp]
     L.vdb_last_error.restype = None
+    L.vdb_hnsw_create.argtypes = [c.c_int, sz, sz, sz, u64, c.c_int, c.POINTER(vp)]
+    L.vdb_hnsw_destroy.argtypes = [vp]
+    L.vdb_hnsw_destroy.restype = None
+    L.vdb_hnsw_add.argtypes = [vp, u64, fp, sz, c.c_long]
+    L.vdb_hnsw_add_bulk.argtypes = [vp, u64p, u64, fp, sz, sz]
+    L.vdb_hnsw_remove.argtypes = [vp, u64]
+    L.vdb_hnsw_search_batch.argtypes = [vp, fp, sz, sz, sz, sz, u64p, fp, szp]
+    L.vdb_hnsw_len.argtypes = [vp]
+    L.vdb_hnsw_len.restype = sz
+    L.vdb_hnsw_metric.argtypes = [vp]
+    L.vdb_hnsw_get_vector.argtypes = [vp, u64, fp, sz, szp]
+    L.vdb_hnsw_neighbors.argtypes = [vp, u64, sz, u64p, sz]
+    L.vdb_hnsw_neighbors.restype = c.c_long
+    L.vdb_hnsw_node_level.argtypes = [vp, u64]
+    L.vdb_hnsw_node_level.restype = c.c_long
+    L.vdb_hnsw_entry_point.argtypes = [vp, u64p, szp]
+    L.vdb_hnsw_stats.argtypes = [vp, u64p]
     L.vdb_abi_version.restype = c.c_int
     L.vdb_build_arch.restype = c.c_char_p
     _lib = L

@@ -258,6 +258,15 @@ struct PairDistParams {
     float* out; uint32_t* status;                                            // ST_NAN / ST_ZERO_QUERY (zero norm on either side)
 };
 void launch_pair_distances(const PairDistParams& p, hipStream_t s);
+// HNSW hooks: zero-norm Cosine pairs are written as the NaN bit pattern `mark` (status is not touched)
+struct PairEvalParams {
+    const float* rows; uint32_t ld; uint32_t dim; const float* nd;
+    const float* qp; const float* qnorm;                 // prepared queries (query side of mode 0 / 2)
+    const uint32_t* a; const uint32_t* b; uint32_t n;    // mode 0: (query a[i], row b[i]); mode 1: (row a[i], row b[i]); mode 2: (query q0, row i)
+    uint32_t q0; int mode; int metric; uint32_t mark;
+    float* out;
+};
+void launch_pair_eval(const PairEvalParams& p, hipStream_t s);
 
 void launch_merge_packed(const int32_t* packed, size_t words_per_part, uint32_t nparts, uint32_t nq, uint32_t k,
                          uint64_t* out_ids, float* out_dists, uint32_t* out_counts, uint32_t* out_status, hipStream_t s);

@@ -948,6 +948,31 @@ void launch_pair_distances(const PairDistParams& p, hipStream_t s) {
     hipLaunchKernelGGL(pair_distances_kernel, dim3((p.n_pairs + 255) / 256), dim3(256), 0, s, p);
 }
 
+// HNSW hooks (vdb_internal.h): exact reference distances of explicit (query, row) or (row, row) pairs, or of one
+// query against rows [0, n); inputs and outputs may live in mapped host memory.
+__global__ __launch_bounds__(256) void pair_eval_kernel(PairEvalParams p) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n) return;
+    const float* x; const float* y; float xn, yn;
+    if (p.mode == 1) {
+        const uint32_t ra = p.a[i], rb = p.b[i];
+        x = p.rows + (size_t)ra * p.ld; xn = p.nd[ra];
+        y = p.rows + (size_t)rb * p.ld; yn = p.nd[rb];
+    } else {
+        const uint32_t q = p.mode == 0 ? p.a[i] : p.q0, r = p.mode == 0 ? p.b[i] : i;
+        x = p.qp + (size_t)q * p.ld; xn = p.qnorm[q];
+        y = p.rows + (size_t)r * p.ld; yn = p.nd[r];
+    }
+    float d;
+    if (p.metric == COSINE && (xn == 0.0f || yn == 0.0f)) d = __uint_as_float(p.mark);
+    else d = exact_distance(p.metric, x, y, p.dim, xn, yn);
+    p.out[i] = d;
+}
+void launch_pair_eval(const PairEvalParams& p, hipStream_t s) {
+    if (!p.n) return;
+    hipLaunchKernelGGL(pair_eval_kernel, dim3((p.n + 255) / 256), dim3(256), 0, s, p);
+}
+
 constexpr uint32_t MERGE_MAX = 2048;
 // part p's arrays start at ids + p*ids_stride, dists + p*dists_stride, counts + p*counts_stride (element units),
 // so both the plain [nparts][nq][k] layout and the packed all-gather buffer of sharded.py can be merged in place

@@ -31,6 +31,7 @@
 
 #include "../../include/vdb_flat.h"
 #include "kernels.h"
+#include "vdb_internal.h"
 
 namespace {
 
@@ -131,6 +132,9 @@ struct vdb_flat_index {
     DevBuf<uint64_t> w2_outi;
     DevBuf<uint32_t> w2_outc, w2_flags, w2_qidx;
     uint32_t* h_flags = nullptr; size_t h_flags_n = 0;
+    // mapped host memory for the pair hooks (vdb_internal.h): the kernel reads the pairs and writes the distances in place
+    uint32_t* h_pairs = nullptr; float* h_pout = nullptr; size_t h_pairs_cap = 0, h_pout_cap = 0;
+    uint32_t pairs_nq = 0;
     int screen = 1;                                         // 1: bf16 screening tier first (default), 0: f32 MFMA tier only
     uint64_t stats[16] = {0};
     bool profile = false; hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -653,6 +657,8 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
     if ((rc = ix->w_flags.ensure(4 + 2 * (size_t)nq32))) return rc;
     if (ix->h_flags_n < 4 + 2 * (size_t)nq32) {
         if (ix->h_flags) (void)hipHostFree(ix->h_flags);
+    if (ix->h_pairs) (void)hipHostFree(ix->h_pairs);
+    if (ix->h_pout) (void)hipHostFree(ix->h_pout);
         ix->h_flags = nullptr;
         ix->h_flags_n = 0;
         size_t want = 4 + 2 * (size_t)nq32 + 1024;
@@ -899,6 +905,8 @@ void vdb_flat_destroy(vdb_flat_index* ix) {
     ix->w2_outi.release(); ix->w2_outc.release(); ix->w2_flags.release(); ix->w2_qidx.release();
     ix->w_cnt.release(); ix->w_subcnt.release(); ix->w_rowmask.release(); ix->w_flags.release(); ix->w_outc.release();
     if (ix->h_flags) (void)hipHostFree(ix->h_flags);
+    if (ix->h_pairs) (void)hipHostFree(ix->h_pairs);
+    if (ix->h_pout) (void)hipHostFree(ix->h_pout);
     if (ix->ev0) { (void)hipEventDestroy(ix->ev0); (void)hipEventDestroy(ix->ev1); }
     (void)hipStreamDestroy(ix->stream);
     delete ix;
@@ -1264,3 +1272,98 @@ int vdb_flat_set_screen(vdb_flat_index* ix, int mode) {
 }
 
 }  // extern "C"
+
+// =================================================================== internal hooks (vdb_internal.h)
+namespace vdb_internal {
+
+static int ensure_pair_buffers(vdb_flat_index* ix, size_t n_pairs, size_t n_out) {
+    if (n_pairs > ix->h_pairs_cap) {
+        if (ix->h_pairs) (void)hipHostFree(ix->h_pairs);
+        ix->h_pairs = nullptr; ix->h_pairs_cap = 0;
+        size_t cap = std::max<size_t>(n_pairs + n_pairs / 2, 4096);
+        HIP_TRY(hipHostMalloc((void**)&ix->h_pairs, cap * 2 * sizeof(uint32_t), hipHostMallocMapped));
+        ix->h_pairs_cap = cap;
+    }
+    if (n_out > ix->h_pout_cap) {
+        if (ix->h_pout) (void)hipHostFree(ix->h_pout);
+        ix->h_pout = nullptr; ix->h_pout_cap = 0;
+        size_t cap = std::max<size_t>(n_out + n_out / 2, 4096);
+        HIP_TRY(hipHostMalloc((void**)&ix->h_pout, cap * sizeof(float), hipHostMallocMapped));
+        ix->h_pout_cap = cap;
+    }
+    return VDB_OK;
+}
+
+int pairs_begin(vdb_flat_index* ix, const float* queries, size_t nq, size_t dim) {
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc;
+    if ((rc = set_device(ix))) return rc;
+    if ((rc = flush(ix))) return rc;
+    ix->pairs_nq = 0;
+    if (nq == 0) return VDB_OK;
+    if (ix->n_live && ix->dim != dim) return fail_dim(dim, ix->dim);
+    if (nq > 0x7fffffffull) return fail(VDB_ERR_INVALID_ARGUMENT, "too many queries");
+    const uint32_t ld = ix->ld ? ix->ld : round_up((uint32_t)dim, vdb::KSTAGE);
+    const uint32_t bp = round_up((uint32_t)nq, SUPER);
+    hipStream_t s = ix->stream;
+    if ((rc = ix->w_qin.ensure(nq * dim))) return rc;
+    if ((rc = ix->w_qp.ensure((size_t)bp * ld))) return rc;
+    if ((rc = ix->w_qnorm.ensure(bp))) return rc;
+    if ((rc = ix->w_thr.ensure(bp))) return rc;
+    if ((rc = ix->w_flags.ensure(4))) return rc;
+    HIP_TRY(hipMemcpyAsync(ix->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    vdb::QueryPrepParams qp{ix->w_qin.p, (uint32_t)dim, (uint32_t)nq, ix->w_qp.p, ld, bp, ix->w_qnorm.p, ix->w_thr.p, vdb::EUCLID,
+                            ix->w_flags.p, nullptr, nullptr};   // metric EUCLID: zero norms are judged per pair
+    vdb::launch_query_prep(qp, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    ix->pairs_nq = (uint32_t)nq;
+    return VDB_OK;
+}
+
+static int run_pair_eval(vdb_flat_index* ix, int mode, const uint32_t* a, const uint32_t* b, uint32_t q0, size_t n, float* out) {
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc;
+    if ((rc = set_device(ix))) return rc;
+    if (n == 0) return VDB_OK;
+    if (n > 0xfffffff0ull) return fail(VDB_ERR_INVALID_ARGUMENT, "too many pairs");
+    if (mode == 1 && (rc = flush(ix))) return rc;
+    if ((rc = ensure_pair_buffers(ix, mode == 2 ? 1 : n, n))) return rc;
+    uint32_t *d_pairs = nullptr; float* d_out = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void**)&d_pairs, ix->h_pairs, 0));
+    HIP_TRY(hipHostGetDevicePointer((void**)&d_out, ix->h_pout, 0));
+    if (mode != 2) {
+        memcpy(ix->h_pairs, a, n * sizeof(uint32_t));
+        memcpy(ix->h_pairs + n, b, n * sizeof(uint32_t));
+    }
+    vdb::PairEvalParams pp{};
+    pp.rows = ix->d_rows; pp.ld = ix->ld; pp.dim = ix->dim; pp.nd = ix->d_nd; pp.qp = ix->w_qp.p; pp.qnorm = ix->w_qnorm.p;
+    pp.a = d_pairs; pp.b = d_pairs + n; pp.n = (uint32_t)n; pp.q0 = q0; pp.mode = mode; pp.metric = ix->metric;
+    pp.mark = ZERO_NORM_MARK; pp.out = d_out;
+    vdb::launch_pair_eval(pp, ix->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    memcpy(out, ix->h_pout, n * sizeof(float));
+    return VDB_OK;
+}
+
+int pairs_eval(vdb_flat_index* ix, const uint32_t* pair_q, const uint32_t* pair_row, size_t n, float* out) {
+    return run_pair_eval(ix, 0, pair_q, pair_row, 0, n, out);
+}
+int rows_eval(vdb_flat_index* ix, const uint32_t* row_a, const uint32_t* row_b, size_t n, float* out) {
+    return run_pair_eval(ix, 1, row_a, row_b, 0, n, out);
+}
+int query_vs_rows(vdb_flat_index* ix, uint32_t q, uint32_t n_rows_, float* out) {
+    if (n_rows_ > ix->n_uploaded) return fail(VDB_ERR_INVALID_ARGUMENT, "rows not uploaded");
+    return run_pair_eval(ix, 2, nullptr, nullptr, q, n_rows_, out);
+}
+uint32_t row_of(vdb_flat_index* ix, uint64_t id) {
+    std::lock_guard<std::mutex> g(ix->mu);
+    auto it = ix->id2row.find(id);
+    return it == ix->id2row.end() ? 0xffffffffu : it->second;
+}
+uint32_t n_rows(vdb_flat_index* ix) { return ix->n_rows(); }
+int set_error(int code, const char* msg) { return fail(code, "%s", msg); }
+int set_dim_error(size_t expected, size_t actual) { return fail_dim(expected, actual); }
+
+}  // namespace vdb_internal

@@ -1,0 +1,469 @@
+// vdb_hnsw.cpp -- host side of include/vdb_hnsw.h: the reference's HNSW graph (src/hnsw/graph.rs) kept on the
+// host, every distance evaluated on the GPU (vdb_internal.h hooks of the device row store).
+//
+// Search: the reference walks one query at a time (graph.rs:386-412).  Here every query of a batch is a resumable
+// traversal; a ROUND advances each of them to its next neighbour expansion (graph.rs:166-193), collects the
+// unvisited neighbours of all of them as (query, row) pairs, evaluates the whole list in one launch, and feeds the
+// distances back in list order.  Each query sees exactly the sequence of heap operations the reference performs, so
+// results are identical to a CPU run on the same graph; only the waiting is shared.
+// Insert: one exact scan of the new vector against the rows already stored (one launch) answers every distance the
+// sequential insert asks for; the prunes of one layer (graph.rs:207-241) are evaluated as one (row, row) batch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/vdb_flat.h"
+#include "../../include/vdb_hnsw.h"
+#include "vdb_internal.h"
+
+namespace {
+
+struct Nb { float d; uint64_t id; };                            // neighbor_queue.rs:7-11
+
+// neighbor_queue.rs:37-43: distance.partial_cmp (unordered -> Equal), then id
+inline int nb_cmp(const Nb& a, const Nb& b) {
+    if (a.d < b.d) return -1;
+    if (a.d > b.d) return 1;
+    return a.id < b.id ? -1 : (a.id > b.id ? 1 : 0);
+}
+
+// Rust's std BinaryHeap (max-heap under SIGN * nb_cmp; SIGN = -1 is BinaryHeap<Reversed>, neighbor_queue.rs:47-60),
+// with the standard library's element moves, so that the backing array -- what into_vec() returns -- is the same.
+template <int SIGN> struct RustHeap {
+    std::vector<Nb> v;
+    static bool le(const Nb& a, const Nb& b) { return SIGN * nb_cmp(a, b) <= 0; }
+    void sift_up(size_t start, size_t pos) {
+        Nb e = v[pos];
+        while (pos > start) {
+            size_t parent = (pos - 1) / 2;
+            if (le(e, v[parent])) break;
+            v[pos] = v[parent];
+            pos = parent;
+        }
+        v[pos] = e;
+    }
+    void push(Nb n) { v.push_back(n); sift_up(0, v.size() - 1); }
+    bool pop(Nb& out) {
+        if (v.empty()) return false;
+        Nb item = v.back();
+        v.pop_back();
+        if (!v.empty()) {
+            std::swap(item, v[0]);
+            const size_t end = v.size();
+            size_t pos = 0, child = 1;
+            Nb e = v[0];
+            while (end >= 2 && child <= end - 2) {                // sift_down_to_bottom
+                if (le(v[child], v[child + 1])) ++child;
+                v[pos] = v[child];
+                pos = child;
+                child = 2 * pos + 1;
+            }
+            if (child == end - 1) { v[pos] = v[child]; pos = child; }
+            v[pos] = e;
+            sift_up(0, pos);
+        }
+        out = item;
+        return true;
+    }
+    size_t size() const { return v.size(); }
+    bool empty() const { return v.empty(); }
+    const Nb& top() const { return v[0]; }
+    void clear() { v.clear(); }
+};
+
+// membership-only id set (graph.rs:151 HashSet<usize>): open addressing, grows by doubling
+struct IdSet {
+    std::vector<uint64_t> t;
+    size_t used = 0;
+    void clear() { t.assign(1024, ~0ull); used = 0; }
+    static size_t h(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; return (size_t)x; }
+    bool insert(uint64_t id) {                                    // true when newly inserted
+        if (t.empty()) clear();
+        if (2 * (used + 1) > t.size()) {
+            std::vector<uint64_t> old; old.swap(t);
+            t.assign(old.size() * 2, ~0ull); used = 0;
+            for (uint64_t x : old) if (x != ~0ull) insert(x);
+        }
+        size_t m = t.size() - 1, i = h(id) & m;
+        while (t[i] != ~0ull) { if (t[i] == id) return false; i = (i + 1) & m; }
+        t[i] = id; ++used;
+        return true;
+    }
+};
+
+struct Node {                                                     // graph.rs:63-72
+    bool present = false;
+    uint32_t level = 0, row = 0xffffffffu;
+    std::vector<std::vector<uint64_t>> nbr;
+};
+
+constexpr float F32_MAX = 3.40282347e+38f;
+inline bool is_zero_norm_mark(float d) { uint32_t b; memcpy(&b, &d, 4); return b == vdb_internal::ZERO_NORM_MARK; }
+
+}  // namespace
+
+struct vdb_hnsw_index {
+    vdb_flat_index* flat = nullptr;
+    int metric = 0;
+    size_t m = 16, m_max0 = 32, ef_construction = 200, ef_search = 50, max_layers = 16;
+    double ml = 0;
+    uint64_t rng = 0;
+    std::vector<Node> nodes;                                      // indexed by id, like the reference's Vec<Option<HnswNode>>
+    bool has_ep = false; uint64_t ep = 0; size_t max_level = 0;
+    size_t count = 0, dim = 0;
+    std::mutex mu;
+    uint64_t stats[4] = {0, 0, 0, 0};
+    const Node* node(uint64_t id) const { return id < nodes.size() && nodes[id].present ? &nodes[id] : nullptr; }
+};
+
+namespace {
+
+using Graph = vdb_hnsw_index;
+
+// One search_layer call (graph.rs:143-199) as a resumable state machine: next_request() runs the loop up to the
+// next batch of distances it needs (entry points first, then one neighbour expansion at a time), feed() consumes them.
+struct LayerSearch {
+    const Graph* g = nullptr;
+    size_t ef = 1, layer = 0;
+    RustHeap<-1> cand;                                            // MinHeap: closest candidate on top
+    RustHeap<+1> res;                                             // MaxHeap: furthest result on top
+    IdSet visited;
+    std::vector<uint64_t> pending;
+    int stage = 0;                                                // 0: entry points not yet requested, 1: requested, 2: main loop
+    bool zero_norm = false;
+
+    void start(const Graph* g_, uint64_t ep, size_t ef_, size_t layer_) {
+        g = g_; ef = ef_; layer = layer_;
+        cand.clear(); res.clear(); visited.clear();
+        pending.assign(1, ep);
+        stage = 0; zero_norm = false;
+    }
+    bool next_request() {
+        if (stage == 0) { stage = 1; return true; }
+        while (true) {
+            Nb c;
+            if (!cand.pop(c)) return false;
+            const float furthest = res.empty() ? F32_MAX : res.top().d;
+            if (c.d > furthest) return false;
+            pending.clear();
+            const Node* n = g->node(c.id);
+            if (n && layer < n->nbr.size()) {
+                for (uint64_t nid : n->nbr[layer]) {
+                    if (!visited.insert(nid)) continue;
+                    if (!g->node(nid)) continue;                  // skip deleted nodes
+                    pending.push_back(nid);
+                }
+            }
+            if (!pending.empty()) return true;
+        }
+    }
+    void feed(const float* d) {
+        for (size_t i = 0; i < pending.size(); ++i) {
+            if (is_zero_norm_mark(d[i])) { zero_norm = true; return; }
+            const Nb n{d[i], pending[i]};
+            if (stage == 1) {
+                visited.insert(n.id);
+                cand.push(n);
+                res.push(n);
+            } else {
+                const float furthest = res.empty() ? F32_MAX : res.top().d;
+                if (n.d < furthest || res.size() < ef) {
+                    cand.push(n);
+                    res.push(n);
+                    if (res.size() > ef) { Nb drop; res.pop(drop); }
+                }
+            }
+        }
+        stage = 2;
+    }
+    std::vector<Nb> sorted() const {                              // into_sorted_vec: backing array, stable sort by distance
+        std::vector<Nb> v = res.v;
+        std::stable_sort(v.begin(), v.end(), [](const Nb& a, const Nb& b) { return a.d < b.d; });
+        return v;
+    }
+};
+
+int zero_norm_error() {
+    return vdb_internal::set_error(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
+}
+
+// graph.rs:118-123
+size_t level_from_unit(const Graph* g, double r) {
+    double v = std::floor(-std::log(r) * g->ml);
+    size_t level = (v >= 1.8446744073709552e19) ? (size_t)-1 : (v != v ? 0 : (size_t)v);
+    return std::min(level, g->max_layers - 1);
+}
+double next_unit(Graph* g) {
+    uint64_t z = (g->rng += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// graph.rs:244-342 with every distance of the insert taken from `scan` (scan[row] = distance(new vector, device row))
+int insert_node(Graph* g, uint64_t id, uint32_t row, long level_in, const float* scan) {
+    const size_t level = level_in >= 0 ? std::min<size_t>((size_t)level_in, g->max_layers - 1) : level_from_unit(g, next_unit(g));
+    if (id >= g->nodes.size()) g->nodes.resize(id + 1);
+    Node& nd = g->nodes[id];
+    nd = Node();
+    nd.present = true; nd.level = (uint32_t)level; nd.row = row;
+    nd.nbr.assign(level + 1, {});
+    g->count++;
+    if (!g->has_ep) { g->has_ep = true; g->ep = id; g->max_level = level; return VDB_OK; }
+    uint64_t ep_id = g->ep;
+    const size_t cur_max = g->max_level;
+    LayerSearch ls;
+    std::vector<float> d;
+    auto run_layer = [&](size_t ef, size_t layer, std::vector<Nb>& out) -> int {
+        ls.start(g, ep_id, ef, layer);
+        while (ls.next_request()) {
+            d.resize(ls.pending.size());
+            for (size_t i = 0; i < d.size(); ++i) d[i] = scan[g->nodes[ls.pending[i]].row];
+            g->stats[0] += d.size();
+            ls.feed(d.data());
+            if (ls.zero_norm) return zero_norm_error();
+        }
+        out = ls.sorted();
+        return VDB_OK;
+    };
+    int rc;
+    std::vector<Nb> nearest;
+    if (cur_max > level)
+        for (size_t l = cur_max; l >= level + 1; --l) {
+            if ((rc = run_layer(1, l, nearest))) return rc;
+            if (!nearest.empty()) ep_id = nearest[0].id;
+        }
+    const size_t from = std::min(level, cur_max);
+    std::vector<uint32_t> pa, pb;
+    std::vector<float> pd;
+    for (size_t l = from;; --l) {
+        const size_t m = l == 0 ? g->m_max0 : g->m;
+        if ((rc = run_layer(g->ef_construction, l, nearest))) return rc;
+        const size_t take = std::min(nearest.size(), m);          // select_neighbors_simple (graph.rs:202-204)
+        std::vector<uint64_t> sel(take);
+        for (size_t i = 0; i < take; ++i) sel[i] = nearest[i].id;
+        g->nodes[id].nbr[l] = sel;
+        // bidirectional links; the prunes of this layer touch disjoint lists, so their distances go out as one batch
+        std::vector<uint64_t> to_prune;
+        for (uint64_t nbid : sel) {
+            Node& nb = g->nodes[nbid];
+            if (nb.present && l < nb.nbr.size()) {
+                nb.nbr[l].push_back(id);
+                if (nb.nbr[l].size() > m) to_prune.push_back(nbid);
+            }
+        }
+        if (!to_prune.empty()) {
+            pa.clear(); pb.clear();
+            for (uint64_t nbid : to_prune)
+                for (uint64_t x : g->nodes[nbid].nbr[l])
+                    if (g->node(x)) { pa.push_back(g->nodes[nbid].row); pb.push_back(g->nodes[x].row); }
+            pd.resize(pa.size());
+            if ((rc = vdb_internal::rows_eval(g->flat, pa.data(), pb.data(), pa.size(), pd.data()))) return rc;
+            g->stats[0] += pa.size(); g->stats[1]++;
+            size_t off = 0;
+            for (uint64_t nbid : to_prune) {                      // graph.rs:207-241 prune_neighbors
+                std::vector<Nb> scored;
+                for (uint64_t x : g->nodes[nbid].nbr[l])
+                    if (g->node(x)) { float dd = pd[off++]; scored.push_back(Nb{is_zero_norm_mark(dd) ? F32_MAX : dd, x}); }
+                std::stable_sort(scored.begin(), scored.end(), [](const Nb& a, const Nb& b) { return a.d < b.d; });
+                if (scored.size() > m) scored.resize(m);
+                std::vector<uint64_t>& lst = g->nodes[nbid].nbr[l];
+                lst.clear();
+                for (const Nb& s : scored) lst.push_back(s.id);
+            }
+        }
+        if (!nearest.empty()) ep_id = nearest[0].id;
+        if (l == 0) break;
+    }
+    if (level > g->max_level) { g->ep = id; g->max_level = level; }
+    return VDB_OK;
+}
+
+int add_rows(Graph* g, const uint64_t* ids, uint64_t first_id, const float* rows, size_t n, size_t dim, const long* levels, long level1) {
+    if (n == 0) return VDB_OK;
+    if (dim == 0) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "zero-dimensional vectors are not indexable");
+    if (g->count == 0 && !g->has_ep) g->dim = dim;
+    if (dim != g->dim) return vdb_internal::set_dim_error(g->dim, dim);
+    int rc;
+    if ((rc = vdb_flat_add_bulk(g->flat, ids, first_id, rows, n, dim))) return rc;
+    std::vector<float> scan;
+    constexpr size_t CHUNK = 256;
+    for (size_t c0 = 0; c0 < n; c0 += CHUNK) {
+        const size_t nc = std::min(CHUNK, n - c0);
+        if ((rc = vdb_internal::pairs_begin(g->flat, rows + c0 * dim, nc, dim))) return rc;   // also uploads the pending rows
+        for (size_t i = 0; i < nc; ++i) {
+            const uint64_t id = ids ? ids[c0 + i] : first_id + c0 + i;
+            const uint32_t row = vdb_internal::row_of(g->flat, id);
+            if (row == 0xffffffffu) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "row was not stored");
+            // every distance this insert can ask for: the new vector against the rows stored before it
+            scan.resize(std::max<size_t>(row, 1));
+            if (row) {
+                if ((rc = vdb_internal::query_vs_rows(g->flat, (uint32_t)i, row, scan.data()))) return rc;
+                g->stats[1]++;
+            }
+            if ((rc = insert_node(g, id, row, levels ? levels[c0 + i] : level1, scan.data()))) return rc;
+        }
+    }
+    return VDB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vdb_hnsw_create(int metric, size_t m, size_t ef_construction, size_t ef_search, uint64_t seed, int device,
+                    vdb_hnsw_index** out) {
+    if (!out) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    if (m < 2) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "m must be >= 2");
+    vdb_flat_index* flat = nullptr;
+    int rc = vdb_flat_create(metric, device, &flat);
+    if (rc) return rc;
+    auto* g = new vdb_hnsw_index();
+    g->flat = flat; g->metric = metric; g->m = m; g->m_max0 = 2 * m; g->ef_construction = ef_construction;
+    g->ef_search = ef_search; g->ml = 1.0 / std::log((double)m); g->rng = seed;              // graph.rs:49-59
+    *out = g;
+    return VDB_OK;
+}
+
+void vdb_hnsw_destroy(vdb_hnsw_index* g) {
+    if (!g) return;
+    vdb_flat_destroy(g->flat);
+    delete g;
+}
+
+int vdb_hnsw_add(vdb_hnsw_index* g, uint64_t id, const float* v, size_t dim, long level) {
+    if (!g || !v) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    return add_rows(g, &id, 0, v, 1, dim, nullptr, level);
+}
+
+int vdb_hnsw_add_bulk(vdb_hnsw_index* g, const uint64_t* ids, uint64_t first_id, const float* rows, size_t n, size_t dim) {
+    if (!g || (!rows && n)) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    return add_rows(g, ids, first_id, rows, n, dim, nullptr, -1);
+}
+
+int vdb_hnsw_remove(vdb_hnsw_index* g, uint64_t id) {             // graph.rs:345-381
+    if (!g) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (!g->node(id)) return VDB_OK;
+    Node gone = std::move(g->nodes[id]);
+    g->nodes[id] = Node();
+    for (size_t l = 0; l < gone.nbr.size(); ++l)
+        for (uint64_t nid : gone.nbr[l]) {
+            if (nid >= g->nodes.size() || !g->nodes[nid].present || l >= g->nodes[nid].nbr.size()) continue;
+            auto& lst = g->nodes[nid].nbr[l];
+            lst.erase(std::remove(lst.begin(), lst.end(), id), lst.end());
+        }
+    g->count--;
+    int rc = vdb_flat_remove(g->flat, id);
+    if (g->has_ep && g->ep == id) {
+        g->has_ep = false; g->max_level = 0;
+        size_t best = 0;
+        for (size_t i = 0; i < g->nodes.size(); ++i)            // max_by_key(level): the LAST of the equally maximal nodes
+            if (g->nodes[i].present && (!g->has_ep || g->nodes[i].level >= best)) { g->has_ep = true; g->ep = i; best = g->nodes[i].level; }
+        g->max_level = g->has_ep ? best : 0;
+    }
+    return rc;
+}
+
+int vdb_hnsw_search_batch(vdb_hnsw_index* g, const float* queries, size_t nq, size_t dim, size_t k, size_t ef,
+                          uint64_t* out_ids, float* out_dists, size_t* out_counts) {
+    if (!g || (nq && (!queries || !out_counts || (k && (!out_ids || !out_dists)))))
+        return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    for (size_t b = 0; b < nq; ++b) out_counts[b] = 0;
+    g->stats[2] = g->stats[3] = 0;
+    if (nq == 0 || !g->has_ep) return VDB_OK;                     // graph.rs:392-395: empty graph -> Ok(vec![])
+    if (dim != g->dim) return vdb_internal::set_dim_error(dim, g->dim);   // distance.rs:21-26 on the first evaluation
+    int rc;
+    if ((rc = vdb_internal::pairs_begin(g->flat, queries, nq, dim))) return rc;
+    const size_t ef_actual = std::max(ef ? ef : g->ef_search, k);
+    struct Q { LayerSearch ls; size_t layer; uint64_t ep; bool done; size_t off, n; };
+    std::vector<Q> qs(nq);
+    for (Q& q : qs) {
+        q.layer = g->max_level; q.ep = g->ep; q.done = false; q.off = q.n = 0;
+        q.ls.start(g, q.ep, q.layer >= 1 ? 1 : ef_actual, q.layer);
+    }
+    std::vector<uint32_t> pq, pr;
+    std::vector<float> pd;
+    while (true) {
+        pq.clear(); pr.clear();
+        for (size_t b = 0; b < nq; ++b) {
+            Q& q = qs[b];
+            q.n = 0;
+            while (!q.done) {
+                if (q.ls.next_request()) {
+                    q.off = pq.size(); q.n = q.ls.pending.size();
+                    for (uint64_t nid : q.ls.pending) { pq.push_back((uint32_t)b); pr.push_back(g->nodes[nid].row); }
+                    break;
+                }
+                // layer finished (graph.rs:399-411)
+                std::vector<Nb> r = q.ls.sorted();
+                if (q.layer >= 1) {
+                    if (!r.empty()) q.ep = r[0].id;
+                    --q.layer;
+                    q.ls.start(g, q.ep, q.layer >= 1 ? 1 : ef_actual, q.layer);
+                } else {
+                    const size_t cnt = std::min(r.size(), k);
+                    for (size_t i = 0; i < cnt; ++i) { out_ids[b * k + i] = r[i].id; out_dists[b * k + i] = r[i].d; }
+                    out_counts[b] = cnt;
+                    q.done = true;
+                }
+            }
+        }
+        if (pq.empty()) break;
+        pd.resize(pq.size());
+        if ((rc = vdb_internal::pairs_eval(g->flat, pq.data(), pr.data(), pq.size(), pd.data()))) return rc;
+        g->stats[0] += pq.size(); g->stats[1]++; g->stats[2]++; g->stats[3] += pq.size();
+        for (size_t b = 0; b < nq; ++b) {
+            Q& q = qs[b];
+            if (q.done || !q.n) continue;
+            q.ls.feed(pd.data() + q.off);
+            if (q.ls.zero_norm) return zero_norm_error();
+        }
+    }
+    return VDB_OK;
+}
+
+size_t vdb_hnsw_len(const vdb_hnsw_index* g) { return g ? g->count : 0; }
+int vdb_hnsw_metric(const vdb_hnsw_index* g) { return g ? g->metric : -1; }
+
+int vdb_hnsw_get_vector(vdb_hnsw_index* g, uint64_t id, float* out, size_t cap, size_t* dim) {
+    if (!g) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (!g->node(id)) return vdb_internal::set_error(VDB_ERR_NOT_FOUND, "Vector not found");
+    return vdb_flat_get_vector(g->flat, id, out, cap, dim);
+}
+
+long vdb_hnsw_neighbors(const vdb_hnsw_index* g, uint64_t id, size_t layer, uint64_t* out, size_t cap) {
+    if (!g) return -1;
+    const Node* n = g->node(id);
+    if (!n || layer >= n->nbr.size()) return -1;
+    for (size_t i = 0; i < n->nbr[layer].size() && i < cap; ++i) out[i] = n->nbr[layer][i];
+    return (long)n->nbr[layer].size();
+}
+long vdb_hnsw_node_level(const vdb_hnsw_index* g, uint64_t id) {
+    const Node* n = g ? g->node(id) : nullptr;
+    return n ? (long)n->level : -1;
+}
+int vdb_hnsw_entry_point(const vdb_hnsw_index* g, uint64_t* id, size_t* max_level) {
+    if (!g) return 0;
+    if (id) *id = g->ep;
+    if (max_level) *max_level = g->max_level;
+    return g->has_ep ? 1 : 0;
+}
+int vdb_hnsw_stats(const vdb_hnsw_index* g, uint64_t out[4]) {
+    if (!g || !out) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    memcpy(out, g->stats, sizeof(g->stats));
+    return VDB_OK;
+}
+
+}  // extern "C"
