@@ -11,10 +11,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/vdb_flat.h"
@@ -392,17 +395,38 @@ int vdb_hnsw_search_batch(vdb_hnsw_index* g, const float* queries, size_t nq, si
         q.layer = g->max_level; q.ep = g->ep; q.done = false; q.off = q.n = 0;
         q.ls.start(g, q.ep, q.layer >= 1 ? 1 : ef_actual, q.layer);
     }
+    // The per-round host work (heap operations, neighbour scans of every in-flight query) is spread over worker
+    // threads, each owning a contiguous block of queries; the GPU evaluates the round's pairs in ONE launch.
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t T = std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)16, std::max<size_t>(nq / 8, 1)});
+    if (const char* e = getenv("VDB_HNSW_THREADS")) T = std::max(1, atoi(e));
+    struct Local { std::vector<uint32_t> pq, pr; size_t base = 0; };
+    std::vector<Local> loc(T);
     std::vector<uint32_t> pq, pr;
     std::vector<float> pd;
-    while (true) {
-        pq.clear(); pr.clear();
-        for (size_t b = 0; b < nq; ++b) {
+    std::atomic<int> arrived{0}, phase{0};
+    std::atomic<bool> stop{false}, zero{false};
+    int rc_eval = VDB_OK;
+    auto barrier = [&]() {                                         // sense-reversing spin barrier over T threads
+        const int ph = phase.load(std::memory_order_acquire);
+        if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (int)T) {
+            arrived.store(0, std::memory_order_relaxed);
+            phase.store(ph + 1, std::memory_order_release);
+        } else {
+            while (phase.load(std::memory_order_acquire) == ph) { /* spin */ }
+        }
+    };
+    auto request_phase = [&](size_t t) {
+        Local& L = loc[t];
+        L.pq.clear(); L.pr.clear();
+        const size_t b0 = nq * t / T, b1 = nq * (t + 1) / T;
+        for (size_t b = b0; b < b1; ++b) {
             Q& q = qs[b];
             q.n = 0;
             while (!q.done) {
                 if (q.ls.next_request()) {
-                    q.off = pq.size(); q.n = q.ls.pending.size();
-                    for (uint64_t nid : q.ls.pending) { pq.push_back((uint32_t)b); pr.push_back(g->nodes[nid].row); }
+                    q.off = L.pq.size(); q.n = q.ls.pending.size();
+                    for (uint64_t nid : q.ls.pending) { L.pq.push_back((uint32_t)b); L.pr.push_back(g->nodes[nid].row); }
                     break;
                 }
                 // layer finished (graph.rs:399-411)
@@ -419,17 +443,50 @@ int vdb_hnsw_search_batch(vdb_hnsw_index* g, const float* queries, size_t nq, si
                 }
             }
         }
-        if (pq.empty()) break;
-        pd.resize(pq.size());
-        if ((rc = vdb_internal::pairs_eval(g->flat, pq.data(), pr.data(), pq.size(), pd.data()))) return rc;
-        g->stats[0] += pq.size(); g->stats[1]++; g->stats[2]++; g->stats[3] += pq.size();
-        for (size_t b = 0; b < nq; ++b) {
+    };
+    auto feed_phase = [&](size_t t) {
+        const size_t b0 = nq * t / T, b1 = nq * (t + 1) / T;
+        for (size_t b = b0; b < b1; ++b) {
             Q& q = qs[b];
             if (q.done || !q.n) continue;
-            q.ls.feed(pd.data() + q.off);
-            if (q.ls.zero_norm) return zero_norm_error();
+            q.ls.feed(pd.data() + loc[t].base + q.off);
+            if (q.ls.zero_norm) zero.store(true, std::memory_order_relaxed);
         }
-    }
+    };
+    auto worker = [&](size_t t) {
+        while (true) {
+            request_phase(t);
+            barrier();
+            if (t == 0) {                                          // the round's pairs of every thread -> one launch
+                size_t total = 0;
+                for (Local& L : loc) { L.base = total; total += L.pq.size(); }
+                if (total == 0) stop.store(true, std::memory_order_release);
+                else {
+                    pq.resize(total); pr.resize(total); pd.resize(total);
+                    for (Local& L : loc)
+                        if (!L.pq.empty()) {
+                            memcpy(pq.data() + L.base, L.pq.data(), L.pq.size() * 4);
+                            memcpy(pr.data() + L.base, L.pr.data(), L.pr.size() * 4);
+                        }
+                    rc_eval = vdb_internal::pairs_eval(g->flat, pq.data(), pr.data(), total, pd.data());
+                    g->stats[0] += total; g->stats[1]++; g->stats[2]++; g->stats[3] += total;
+                    if (rc_eval) stop.store(true, std::memory_order_release);
+                }
+            }
+            barrier();
+            if (stop.load(std::memory_order_acquire)) return;
+            feed_phase(t);
+            if (zero.load(std::memory_order_relaxed)) { /* every thread sees it after the next barrier */ }
+            barrier();
+            if (zero.load(std::memory_order_acquire)) return;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < T; ++t) pool.emplace_back(worker, t);
+    worker(0);
+    for (std::thread& th : pool) th.join();
+    if (rc_eval) return rc_eval;
+    if (zero.load()) return zero_norm_error();
     return VDB_OK;
 }
 
