@@ -111,6 +111,41 @@ int main() {
         ix.add(1, Vector{0, 0});
         try { ix.search(Vector{1, 1}, 1); CHECK(false); } catch (const VectorDbError& e) { CHECK(e.kind == VectorDbError::InvalidVector); }
     }
+    {   // src/hnsw/mod.rs:88-108  HnswIndex through the trait; get_vector
+        GpuHnswIndex ix(DistanceMetric::Euclidean);
+        ix.add(0, Vector{1.f, 0.f, 0.f});
+        ix.add(1, Vector{0.f, 1.f, 0.f});
+        ix.add(2, Vector{1.f, 1.f, 0.f});
+        auto r = ix.search(Vector{1.f, 0.f, 0.f}, 2);
+        CHECK(r.size() == 2 && r[0].first == 0 && r[0].second < 1e-5f);
+        CHECK(ix.get_vector(0) && *ix.get_vector(0) == (Vector{1.f, 0.f, 0.f}) && ix.get_vector(99) == nullptr);
+    }
+    {   // src/hnsw/graph.rs:488-537  search_knn, remove, remove the entry point
+        GpuHnswIndex g(DistanceMetric::Euclidean, HnswParams::make(4, 32, 16));
+        for (size_t i = 0; i < 5; ++i) g.add(i, Vector{(float)i, 0.f});
+        auto r = g.search_with_ef(Vector{0.5f, 0.f}, 2, 16);
+        CHECK(r.size() == 2 && ((r[0].first == 0 && r[1].first == 1) || (r[0].first == 1 && r[1].first == 0)));
+        GpuHnswIndex h(DistanceMetric::Euclidean, HnswParams::make(4, 32, 16));
+        h.add(0, Vector{1.f, 0.f});
+        h.add(1, Vector{0.f, 1.f});
+        h.remove(0);
+        CHECK(h.len() == 1 && h.search_with_ef(Vector{0.f, 1.f}, 1, 16).at(0).first == 1);
+        uint64_t ep = 0;
+        h.add(2, Vector{1.f, 1.f});
+        CHECK(vdb_hnsw_entry_point(h.handle(), &ep, nullptr) == 1);
+        h.remove((size_t)ep);
+        CHECK(h.len() == 1 && !h.search_with_ef(Vector{0.f, 1.f}, 1, 16).empty());
+    }
+    {   // src/hnsw/mod.rs:111-153  HnswIndex behind the VectorStore
+        VectorStore<GpuHnswIndex> st(std::make_unique<GpuHnswIndex>(DistanceMetric::Euclidean, HnswParams::make(4, 32, 16)));
+        st.insert("v1", Vector{1, 0, 0});
+        st.insert("v2", Vector{0, 1, 0});
+        st.insert("v3", Vector{0, 0, 1});
+        auto r = st.search(Vector{1.f, 0.1f, 0.f}, 2);
+        CHECK(r.size() == 2 && r[0].id == "v1");
+        st.remove("v1");
+        CHECK(st.len() == 2);
+    }
     std::puts("host mirror ok");
     return 0;
 }

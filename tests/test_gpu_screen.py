@@ -147,18 +147,35 @@ def test_near_duplicates_within_bf16_resolution(vdb):
         check_oracle(metric, rows, q, 10, a, range(3))
 
 
-def test_clustered_row_order_overflows_pools_and_still_matches(vdb):
-    """All near neighbours sit in ONE row range (one workgroup's private pools overflow): the overflow flag must
-    route those queries to the next tiers."""
+def test_clustered_row_order_stays_on_the_screen_tier(vdb):
+    """All near neighbours sit in ONE row range (data stored cluster by cluster): nearly every key that passes the
+    threshold lands in one workgroup's private sub-pools.  They are sized for that (4 x 256 slots per query and
+    workgroup), so the query is still answered -- and certified -- by the screening tier."""
     rng = np.random.default_rng(24)
-    n, d = 100000, 32
-    rows = rng.standard_normal((n, d)).astype(np.float32) * 10.0
-    rows[5000:5300] = 0.01 * rng.standard_normal((300, d)).astype(np.float32) + 1.0   # a tight cluster of 300 rows
-    q = (np.ones((3, d)) + 0.001 * rng.standard_normal((3, d))).astype(np.float32)
+    n, d = 200000, 32
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    centre = rng.standard_normal(d).astype(np.float32)
+    rows[5000:5300] = centre + 0.3 * rng.standard_normal((300, d)).astype(np.float32)  # a cluster of 300 rows, stored together
+    q = (centre + 0.05 * rng.standard_normal((3, d))).astype(np.float32)
+    ix = make_index(vdb, 0, rows)
+    a, st, b = both_tiers(ix, q, 10)
+    assert st["bf16_screen"] == 1 and st["pool_overflows"] == 0 and st["exact_queries"] == 0, st
+    assert same(a, b)
+    check_oracle(0, rows, q, 10, a, range(3))
+
+
+def test_pool_overflow_is_routed_to_the_next_tiers(vdb):
+    """More near-duplicates in one tile than a sub-pool can hold (2000 copies of one row): the overflow flag must send
+    the query on, and the answer must still be the oracle's (distance, then id)."""
+    rng = np.random.default_rng(27)
+    n, d = 100000, 16
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[30000:32000] = rows[30000]                                                    # 2000 identical rows
+    q = np.stack([rows[30000], rows[30000] + 1e-3]).astype(np.float32)
     ix = make_index(vdb, 0, rows)
     a, st, b = both_tiers(ix, q, 10)
     assert same(a, b)
-    check_oracle(0, rows, q, 10, a, range(3))
+    check_oracle(0, rows, q, 10, a, range(2))
 
 
 def test_tombstones_overwrites_and_prefilter_under_the_screen_tier(vdb):

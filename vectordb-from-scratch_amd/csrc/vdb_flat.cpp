@@ -547,7 +547,11 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
     const uint32_t n = ix->n_uploaded, ld = ix->ld;
     const uint32_t S = pl.S, kp = pl.kp, KT = pl.kt;
     const uint32_t M = vdb::fused_bf16_sample_groups(S);
-    const uint32_t capl = 64;
+    // private sub-pools of 256 slots: when the rows near a query are stored next to each other (data ordered by
+    // cluster) most of the ~N*kt/S keys that pass land in ONE workgroup's four sub-pools; 4 x 256 slots hold about twice
+    // the expected total, so that case stays on this tier instead of overflowing into the next.  The gather reads
+    // counts and keys, never empty slots, so the capacity costs address space only (0.5 GB of workspace at 1M rows).
+    const uint32_t capl = 256;
     const uint32_t n_wg = std::min<uint32_t>((uint32_t)ix->n_cu, (n + vdb::fused_bf16_tile_rows() - 1) / vdb::fused_bf16_tile_rows());
     const uint32_t n_sub = vdb::fused_bf16_subpools_per_query(n_wg);
     if ((rc = ix->w_dense.ensure((size_t)SUPER * M))) return rc;

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "vdb_flat.h"
+#include "vdb_hnsw.h"
 
 namespace vdb_host {
 
@@ -149,6 +150,87 @@ private:
     vdb_flat_index* h_ = nullptr;
     DistanceMetric metric_;
     std::unordered_map<size_t, Vector> vectors_;                                 // host copy for get_vector() borrows
+};
+
+struct HnswParams {                                                             // graph.rs:19-59
+    size_t m = 16, ef_construction = 200, ef_search = 50;
+    static HnswParams make(size_t m, size_t efc, size_t efs) { HnswParams p; p.m = m; p.ef_construction = efc; p.ef_search = efs; return p; }
+};
+
+// Drop-in for HnswIndex (src/hnsw/mod.rs:14-82) over include/vdb_hnsw.h: the library runs the reference's graph
+// traversal, every distance is evaluated on the GPU.  `seed` replaces StdRng::from_entropy() (graph.rs:101).
+class GpuHnswIndex : public Index {
+public:
+    explicit GpuHnswIndex(DistanceMetric m, HnswParams p = HnswParams(), uint64_t seed = 1, int device = 0) : metric_(m) {
+        check(vdb_hnsw_create((int)m, p.m, p.ef_construction, p.ef_search, seed, device, &h_));
+    }
+    ~GpuHnswIndex() override { vdb_hnsw_destroy(h_); }
+    GpuHnswIndex(const GpuHnswIndex&) = delete;
+    GpuHnswIndex& operator=(const GpuHnswIndex&) = delete;
+    GpuHnswIndex(GpuHnswIndex&& o) noexcept : h_(o.h_), metric_(o.metric_), vectors_(std::move(o.vectors_)) { o.h_ = nullptr; }
+
+    void add(size_t id, Vector v) override {                                    // mod.rs:57-59
+        check(vdb_hnsw_add(h_, id, v.as_slice().data(), v.dimension(), -1));
+        vectors_[id] = std::move(v);
+    }
+    void remove(size_t id) override {                                           // mod.rs:61-63
+        check(vdb_hnsw_remove(h_, id));
+        vectors_.erase(id);
+    }
+    const Vector* get_vector(size_t id) const override {                        // mod.rs:65-67
+        auto it = vectors_.find(id);
+        return it == vectors_.end() ? nullptr : &it->second;
+    }
+    std::vector<Neighbor> search(const Vector& q, size_t k) const override { return search_with_ef(q, k, 50); }   // mod.rs:69-72
+    std::vector<Neighbor> search_with_ef(const Vector& q, size_t k, size_t ef) const {                            // mod.rs:45-53
+        std::vector<uint64_t> ids(std::max<size_t>(k, 1));
+        std::vector<float> ds(ids.size());
+        size_t n = 0;
+        check(vdb_hnsw_search_batch(h_, q.as_slice().data(), 1, q.dimension(), k, ef, ids.data(), ds.data(), &n));
+        std::vector<Neighbor> out;
+        for (size_t i = 0; i < n; ++i) out.emplace_back((size_t)ids[i], ds[i]);
+        return out;
+    }
+    // all queries walk the graph in lockstep: one GPU launch per traversal round for all their candidate lists
+    std::vector<std::vector<Neighbor>> search_batch(const std::vector<std::pair<Vector, size_t>>& qs) const override {
+        std::vector<std::vector<Neighbor>> out(qs.size());
+        if (qs.empty()) return out;
+        const size_t dim = qs[0].first.dimension();
+        size_t kmax = 1;
+        std::vector<float> flat;
+        for (auto& q : qs) {
+            if (q.first.dimension() != dim) return Index::search_batch(qs);     // ragged batch: the sequential loop
+            flat.insert(flat.end(), q.first.as_slice().begin(), q.first.as_slice().end());
+            kmax = std::max(kmax, q.second);
+        }
+        std::vector<uint64_t> ids(qs.size() * kmax);
+        std::vector<float> ds(qs.size() * kmax);
+        std::vector<size_t> cnt(qs.size());
+        check(vdb_hnsw_search_batch(h_, flat.data(), qs.size(), dim, kmax, 50, ids.data(), ds.data(), cnt.data()));
+        for (size_t b = 0; b < qs.size(); ++b)
+            for (size_t i = 0; i < std::min(cnt[b], qs[b].second); ++i) out[b].emplace_back((size_t)ids[b * kmax + i], ds[b * kmax + i]);
+        return out;
+    }
+    void build_batch(const std::vector<std::pair<size_t, Vector>>& vs) { for (auto& v : vs) add(v.first, v.second); }   // mod.rs:37-42
+    DistanceMetric metric() const override { return metric_; }
+    size_t len() const override { return vdb_hnsw_len(h_); }
+    vdb_hnsw_index* handle() const { return h_; }
+
+private:
+    static void check(int rc) {
+        if (rc == VDB_OK) return;
+        char buf[512];
+        size_t e = 0, a = 0;
+        vdb_last_error(buf, sizeof buf, &e, &a);
+        switch (rc) {
+        case VDB_ERR_DIMENSION_MISMATCH: throw VectorDbError::dimension_mismatch(e, a);
+        case VDB_ERR_INVALID_VECTOR: throw VectorDbError(VectorDbError::InvalidVector, buf);
+        default: throw VectorDbError(VectorDbError::IndexError, std::string("Index error: ") + buf);
+        }
+    }
+    vdb_hnsw_index* h_ = nullptr;
+    DistanceMetric metric_;
+    std::unordered_map<size_t, Vector> vectors_;
 };
 
 struct SearchResult { std::string id; float distance; };                        // storage.rs:13-16
