@@ -101,7 +101,7 @@ def test_full_size_prefilter_and_k30(big):
 
 @pytest.mark.parametrize("screen", [1, 0], ids=["bf16-screen", "f32-tier"])
 def test_full_size_k100_stays_on_the_mfma_path(big, screen):
-    """Config-3 style k = 100 (f32 tier: kp = 128; screening tier: up to 256 candidates): the sample must be sized
+    """Config-3 style k = 100 (f32 tier: kp = 128; screening tier: up to 512 candidates): the sample must be sized
     so that no pool overflows and every query is certified by an MFMA tier (a too-small sample once sent 1019 of
     1024 queries to the exact fallback)."""
     vdb, rows, queries = big["vdb"], big["rows"], big["queries"]
@@ -109,7 +109,7 @@ def test_full_size_k100_stays_on_the_mfma_path(big, screen):
     q_h = queries[:64].cpu().numpy()
     gi, gd, gc = ix.search_batch_arrays(q_h, 100)
     st = ix.last_stats()
-    assert st["kprime"] == (256 if screen else 128) and st["exact_queries"] == 0 and st["pool_overflows"] == 0, st
+    assert st["kprime"] == (512 if screen else 128) and st["exact_queries"] == 0 and st["pool_overflows"] == 0, st
     assert np.all(gc == 100)
     rows_h = rows.cpu().numpy()
     for b in (3, 40):

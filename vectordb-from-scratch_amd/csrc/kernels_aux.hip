@@ -574,7 +574,7 @@ __device__ __forceinline__ bool cert_test(const RerankParams& p, uint32_t q, flo
 
 typedef __attribute__((address_space(3))) void* rr_lds_t;
 typedef const __attribute__((address_space(1))) void* rr_glb_t;
-constexpr uint32_t RR_MAX = 256;        // candidates per query at most
+constexpr uint32_t RR_MAX = 512;        // candidates per query at most (= RR_THREADS: one thread per candidate)
 constexpr uint32_t RR_THREADS = 512;
 
 __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
     __shared__ uint32_t sDist[RR_MAX];    // ordered exact distance
     __shared__ uint64_t sId[RR_MAX];
     __shared__ uint32_t sRowIdx[RR_MAX];
-    __shared__ uint32_t sAnyNan, sNanKey, sNext, sRealW[4];
+    __shared__ uint32_t sAnyNan, sNanKey, sNext, sRealW[RR_THREADS / 64];
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t cnt = p.cand_cnt[q] < p.kp ? p.cand_cnt[q] : p.kp;
     const uint64_t* cand = p.cand + (size_t)q * p.cand_stride;
@@ -667,7 +667,9 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
             if (lane == 0) sRealW[wv] = (uint32_t)__popcll(b0);
         }
         __syncthreads();
-        const uint32_t real = sRealW[0] + sRealW[1] + sRealW[2] + sRealW[3];
+        uint32_t real = 0;
+#pragma unroll
+        for (uint32_t w8 = 0; w8 < RR_THREADS / 64; ++w8) real += sRealW[w8];
         nout = real < p.k ? real : p.k;
         // ---- certification / how much deeper to go
         const bool clean = !sNanKey && real == processed;          // no NaN score, no ineligible candidate so far

@@ -389,7 +389,8 @@ Bf16Plan plan_bf16(uint32_t n, size_t k) {
     uint32_t kt = std::min<uint32_t>(want_kt, (uint32_t)(S / 256u));
     if (const char* e = getenv("VDB_KT16")) kt = std::min<uint32_t>((uint32_t)std::max(1, atoi(e)), (uint32_t)(S / 256u));
     if (kt < k + 1 || kt < 16) return pl;
-    pl.kp = 256; pl.S = (uint32_t)S; pl.kt = kt;
+    pl.kp = k > 48 ? 512 : 256;                                  // candidates the select delivers (depth limit of the re-rank)
+    pl.S = (uint32_t)S; pl.kt = kt;
     while ((1ull << pl.shift) < S) ++pl.shift;
     return pl;
 }
