@@ -89,6 +89,7 @@ struct QueryPrepParams {
     uint32_t* status;
     uint16_t* qb;                                      // may be null: [nq_pad][ld] bf16 (RNE) copy for the screening tier
     float* qerr;                                       // with qb: |q - bf16(q)| per query (upper bound)
+    uint32_t* clear_a; uint32_t* clear_b;              // may be null: per-query flag words this kernel zeroes (cert, overflow)
 };
 void launch_query_prep(const QueryPrepParams& p, hipStream_t s);
 

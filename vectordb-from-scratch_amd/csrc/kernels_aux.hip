@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepParams p) {
         }
         p.qnorm[q] = n;
         if (q >= p.nq) p.thr[q] = __uint_as_float(0xff800000u);   // -inf
+        if (q < p.nq && p.clear_a) { p.clear_a[q] = 0u; p.clear_b[q] = 0u; }
     }
 }
 void launch_query_prep(const QueryPrepParams& p, hipStream_t s) {

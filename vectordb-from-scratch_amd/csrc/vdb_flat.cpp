@@ -132,6 +132,7 @@ struct vdb_flat_index {
     DevBuf<uint64_t> w2_outi;
     DevBuf<uint32_t> w2_outc, w2_flags, w2_qidx;
     uint32_t* h_flags = nullptr; size_t h_flags_n = 0;
+    bool status_dirty = true; uint32_t* status_buf = nullptr;   // device status block known to be zero?
     // mapped host memory for the pair hooks (vdb_internal.h): the kernel reads the pairs and writes the distances in place
     uint32_t* h_pairs = nullptr; float* h_pout = nullptr; size_t h_pairs_cap = 0, h_pout_cap = 0;
     uint32_t pairs_nq = 0;
@@ -673,7 +674,15 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
     uint32_t* d_status = ix->w_flags.p;        // [0] status bits
     uint32_t* d_cert = ix->w_flags.p + 4;      // [nq]
     uint32_t* d_ovf = d_cert + nq32;           // [nq]
-    HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, (4 + 2 * (size_t)nq32) * 4, s));
+    // the per-query flags are zeroed by query_prep; the 16-byte status block only needs a memset when the last
+    // search left it set (or the buffer is new) -- one launch less at the head of every search
+    const bool flags_by_prep = kp != 0 || (ix->screen && plan_bf16(n, k).kp);
+    if (!flags_by_prep) HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, (4 + 2 * (size_t)nq32) * 4, s));
+    else if (ix->status_dirty || ix->w_flags.p != ix->status_buf) {
+        HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, 16, s));
+        ix->status_buf = ix->w_flags.p;
+    }
+    ix->status_dirty = true;                               // until a clean status word has been read back
 
     // ---- eligibility mask: tombstones, optionally AND the caller's id filter
     const uint32_t* d_rowmask = (ix->n_live == n) ? nullptr : ix->d_live;
@@ -692,7 +701,7 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
             qb = ix->w_qb.p;
         }
         vdb::QueryPrepParams qp{d_q, (uint32_t)dim, nq32, ix->w_qp.p, ld, bp_all, ix->w_qnorm.p, ix->w_thr.p, ix->metric, d_status, qb,
-                                ix->w_qerr.p};
+                                ix->w_qerr.p, flags_by_prep ? d_cert : nullptr, flags_by_prep ? d_ovf : nullptr};
         vdb::launch_query_prep(qp, s);
     }
 
@@ -732,6 +741,8 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, (4 + 2 * (size_t)nq32) * 4, hipMemcpyDeviceToHost, s));
     ix->stats[10] = since();                       // host time until everything of the first tier is enqueued, ns
+    static const int spin_mode = getenv("VDB_SPIN") ? atoi(getenv("VDB_SPIN")) : 0;
+    if (spin_mode == 1) { while (hipStreamQuery(s) == hipErrorNotReady) { } }
     HIP_TRY(hipStreamSynchronize(s));
     ix->stats[11] = since();                       // ... until the first tier's flags are on the host, ns
     uint32_t status = ix->h_flags[0];
@@ -842,6 +853,7 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
         HIP_TRY(hipStreamSynchronize(s));
         st2 |= ix->h_flags[0];
     }
+    ix->status_dirty = st2 != 0;
     if (st2 & vdb::ST_NAN)
         return fail(VDB_ERR_NAN, "NaN distance (the reference panics here, flat_index.rs:62)");
     return VDB_OK;
@@ -1214,7 +1226,7 @@ int vdb_flat_distances_batch(vdb_flat_index* ix, const float* queries, size_t nq
     HIP_TRY(hipMemcpyAsync(ix->w_rowmask.p, prow.data(), total * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ix->w_rowmask.p + total, pq.data(), total * 4, hipMemcpyHostToDevice, s));
     vdb::QueryPrepParams qp{ix->w_qin.p, (uint32_t)dim, nq32, ix->w_qp.p, ld, bp, ix->w_qnorm.p, ix->w_thr.p, vdb::EUCLID,
-                            ix->w_flags.p, nullptr, nullptr};   // metric EUCLID here: zero norms are judged per PAIR below
+                            ix->w_flags.p, nullptr, nullptr, nullptr, nullptr};   // metric EUCLID here: zero norms are judged per PAIR below
     vdb::launch_query_prep(qp, s);
     vdb::PairDistParams pp{ix->d_rows, ld, (uint32_t)dim, ix->w_qp.p, ix->w_qnorm.p, ix->d_nd, ix->w_rowmask.p + total,
                            ix->w_rowmask.p, (uint32_t)total, ix->metric, ix->w_outd.p, ix->w_flags.p};
@@ -1318,7 +1330,7 @@ int pairs_begin(vdb_flat_index* ix, const float* queries, size_t nq, size_t dim)
     if ((rc = ix->w_flags.ensure(4))) return rc;
     HIP_TRY(hipMemcpyAsync(ix->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
     vdb::QueryPrepParams qp{ix->w_qin.p, (uint32_t)dim, (uint32_t)nq, ix->w_qp.p, ld, bp, ix->w_qnorm.p, ix->w_thr.p, vdb::EUCLID,
-                            ix->w_flags.p, nullptr, nullptr};   // metric EUCLID: zero norms are judged per pair
+                            ix->w_flags.p, nullptr, nullptr, nullptr, nullptr};   // metric EUCLID: zero norms are judged per pair
     vdb::launch_query_prep(qp, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
