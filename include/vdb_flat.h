@@ -154,6 +154,19 @@ int vdb_merge_topk_device(int device, const uint64_t *d_part_ids, const float *d
                           uint64_t *d_out_ids, float *d_out_dists, uint32_t *d_out_counts,
                           void *stream);
 
+/* The device-resident search in two halves, for callers that have more work to enqueue behind it (the multi-GPU
+ * exchange of sharded.py): _begin runs every check and enqueues the FIRST tier on `stream` without synchronising the
+ * host; *d_code (device word, may be NULL) receives 0 when every query was certified by that tier and no error status
+ * was raised, else VDB_PENDING_HOST.  _finish waits for the stream, runs the fallback tiers for the queries that need
+ * them (*changed = 1 when outputs were rewritten) and reports the errors a plain vdb_flat_search_batch_device call
+ * would.  The handle stays locked between the two calls, which must come from the same thread; every _begin that
+ * returned VDB_OK must be followed by one _finish. */
+#define VDB_PENDING_HOST 100
+int vdb_flat_search_batch_device_begin(vdb_flat_index *h, const float *d_queries, size_t nq, size_t dim, size_t k,
+                                       const uint64_t *d_id_mask, size_t mask_bits, uint64_t *d_out_ids,
+                                       float *d_out_dists, uint32_t *d_out_counts, int32_t *d_code, void *stream);
+int vdb_flat_search_batch_device_finish(vdb_flat_index *h, int *changed);
+
 /* The same merge reading the all-gathered exchange buffer in place.  Each part is `words_per_part` int32
  * words (even): ids int64[nq*k] | dists f32[nq*k] | counts i32[nq] | status i32 | pad.  *d_out_status (may be
  * NULL) receives the maximum status word over the parts, so one host read tells whether any shard failed. */

@@ -83,3 +83,65 @@ def test_packed_exchange_buffer_merge():
     for b in range(B):
         assert out_i[b, :n[b]].cpu().tolist() == ti[b, :n[b]].tolist()
         assert torch.equal(out_d[b, :n[b]].cpu(), td[b, :n[b]])
+
+
+def test_two_half_search_for_the_single_sync_exchange():
+    """vdb_flat_search_batch_device_begin / _finish: the first tier is only enqueued, a device word tells whether the
+    host still has work (uncertified queries, errors), finish() then does exactly what the plain call would."""
+    vdb = load_package()
+    vdb.build()
+    rng = np.random.default_rng(77)
+    n, d, B, k = 90_000, 40, 21, 10
+    dev = torch.device("cuda", 0)
+
+    def run(ix, q):
+        q_t = torch.from_numpy(q).to(dev)
+        ids = torch.empty((B, k), dtype=torch.int64, device=dev)
+        ds = torch.empty((B, k), dtype=torch.float32, device=dev)
+        cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+        code = torch.full((1,), -7, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ix.search_batch_device_begin(q_t.data_ptr(), B, d, k, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(), code_ptr=code.data_ptr())
+        first = int(code.item())                                # ordered behind the search by the begin call itself
+        changed = ix.search_batch_device_finish()
+        torch.cuda.synchronize()
+        return first, changed, ids.cpu().numpy().astype(np.uint64), ds.cpu().numpy(), cnt.cpu().numpy()
+
+    # clean batch: code 0, nothing rewritten, results = the plain call = the oracle
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    ix = vdb.GpuFlatIndex(vdb.DistanceMetric(0), keep_host_copy=False)
+    ix.add_bulk(rows)
+    first, changed, gi, gd, gc = run(ix, q)
+    assert first == 0 and changed is False
+    pi, pdist, pc = ix.search_batch_arrays(q, k)
+    assert np.array_equal(gi, pi) and np.array_equal(gd.view(np.uint32), pdist.view(np.uint32)) and np.all(gc == k)
+    oi, od = oracle.flat_search(0, rows, q[3], k)
+    assert np.array_equal(gi[3], oi) and np.array_equal(gd[3], od)
+    # exact ties beyond the re-rank depth (every row 300 times, depth 256): nothing can be certified on the device
+    # -> VDB_PENDING_HOST, finish() rewrites
+    base = rng.random((300, d), dtype=np.float32)
+    rows2 = np.concatenate([base] * 300, 0)
+    q2 = np.ascontiguousarray(np.tile(base[:3], (7, 1))[:B])
+    ix2 = vdb.GpuFlatIndex(vdb.DistanceMetric(0), keep_host_copy=False)
+    ix2.add_bulk(rows2)
+    first, changed, gi, gd, gc = run(ix2, q2)
+    assert first == 100 and changed is True
+    for b in (0, 1, 20):
+        oi, od = oracle.flat_search(0, rows2, q2[b], k)
+        assert np.array_equal(gi[b], oi) and np.array_equal(gd[b], od)
+    # a zero-norm query under Cosine: found on the device -> code 100, finish() raises like the plain call
+    ix3 = vdb.GpuFlatIndex(vdb.DistanceMetric(1), keep_host_copy=False)
+    ix3.add_bulk(rows)
+    qz = q.copy()
+    qz[5] = 0.0
+    q_t = torch.from_numpy(qz).to(dev)
+    ids = torch.empty((B, k), dtype=torch.int64, device=dev); ds = torch.empty((B, k), dtype=torch.float32, device=dev)
+    cnt = torch.empty((B,), dtype=torch.int32, device=dev); code = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ix3.search_batch_device_begin(q_t.data_ptr(), B, d, k, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr(), code_ptr=code.data_ptr())
+    assert int(code.item()) == 100
+    with pytest.raises(vdb.InvalidVector):
+        ix3.search_batch_device_finish()
+    assert len(ix3.search(vdb.Vector(q[0]), 3)) == 3            # the handle is unlocked and usable again
+    with pytest.raises(vdb.VectorDbError):
+        ix3.search_batch_device_finish()                        # no search pending

@@ -117,6 +117,7 @@ struct SelectParams {
     uint32_t* out_cnt;
     float* out_thr;                                    // may be null: score of the kk-th key, +inf if fewer
     uint32_t* ovf;                                     // may be null: set when counts[q] > cap
+    uint32_t* summary;                                 // may be null: OR-ed with 2 whenever an overflow flag is set
     const uint64_t* lo_excl;                           // may be null: only keys > lo_excl[q] take part (chunked large k)
     uint64_t* out_last;                                // may be null: largest selected key per query (unchanged if none)
 };
@@ -268,6 +269,10 @@ struct PairEvalParams {
     float* out;
 };
 void launch_pair_eval(const PairEvalParams& p, hipStream_t s);
+
+// *code = VDB_PENDING_HOST (100) when the status block of a search (flags[0] status bits, flags[1] summary of
+// uncertified / overflowed queries) is non-zero, else 0
+void launch_write_code(const uint32_t* flags, int32_t* code, hipStream_t s);
 
 void launch_merge_packed(const int32_t* packed, size_t words_per_part, uint32_t nparts, uint32_t nq, uint32_t k,
                          uint64_t* out_ids, float* out_dists, uint32_t* out_counts, uint32_t* out_status, hipStream_t s);

@@ -381,14 +381,14 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
                 }
             }
         }
-        if (over && p.ovf) p.ovf[q] = 1u;
+        if (over && p.ovf) { p.ovf[q] = 1u; if (p.summary) atomicOr(p.summary, 2u); }
         __syncthreads();
         n = sN < SEL_LDS_KEYS ? sN : SEL_LDS_KEYS;
         cached = true;
     } else {
         if (p.counts) {
             uint32_t c = p.counts[q];
-            if (c > p.cap) { c = p.cap; if (p.ovf && tid == 0) p.ovf[q] = 1u; }
+            if (c > p.cap) { c = p.cap; if (p.ovf && tid == 0) { p.ovf[q] = 1u; if (p.summary) atomicOr(p.summary, 2u); } }
             n = c;
         }
         cached = n <= SEL_LDS_KEYS;
@@ -719,6 +719,7 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
         p.out_counts[q] = nout;
         if (sAnyNan) atomicOr(p.status, ST_NAN);
         p.cert[q] = cert;
+        if (!cert) atomicOr(p.status + 1, 1u);             // summary word of the status block: some query needs the next tier
         if (p.depth) p.depth[q] = processed;
     }
 }
@@ -974,6 +975,11 @@ __global__ __launch_bounds__(256) void pair_eval_kernel(PairEvalParams p) {
 void launch_pair_eval(const PairEvalParams& p, hipStream_t s) {
     if (!p.n) return;
     hipLaunchKernelGGL(pair_eval_kernel, dim3((p.n + 255) / 256), dim3(256), 0, s, p);
+}
+
+__global__ void write_code_kernel(const uint32_t* flags, int32_t* code) { *code = (flags[0] | flags[1]) ? 100 : 0; }
+void launch_write_code(const uint32_t* flags, int32_t* code, hipStream_t s) {
+    hipLaunchKernelGGL(write_code_kernel, dim3(1), dim3(1), 0, s, flags, code);
 }
 
 constexpr uint32_t MERGE_MAX = 2048;

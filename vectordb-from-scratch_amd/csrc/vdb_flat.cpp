@@ -136,6 +136,19 @@ struct vdb_flat_index {
     // mapped host memory for the pair hooks (vdb_internal.h): the kernel reads the pairs and writes the distances in place
     uint32_t* h_pairs = nullptr; float* h_pout = nullptr; size_t h_pairs_cap = 0, h_pout_cap = 0;
     uint32_t pairs_nq = 0;
+    // a search between its two halves (search_part1 enqueues the first tier, search_part2 reads its flags and runs
+    // the fallback tiers): vdb_flat_search_batch_device_begin / _finish keep the handle locked in between
+    struct SearchCtx {
+        bool pending = false;                               // part 2 still has to run
+        uint32_t nq32 = 0, kp = 0, kp16 = 0;
+        size_t k = 0;
+        hipStream_t s = nullptr;
+        const uint32_t* d_rowmask = nullptr;
+        uint64_t* d_out_ids = nullptr; float* d_out_dists = nullptr; uint32_t* d_out_counts = nullptr;
+        std::chrono::steady_clock::time_point t_entry;
+    } ctx;
+    bool begin_locked = false;
+    hipEvent_t ev_order = nullptr;                          // orders the handle's stream before the null stream (search_batch_device_begin)
     int screen = 1;                                         // 1: bf16 screening tier first (default), 0: f32 MFMA tier only
     uint64_t stats[16] = {0};
     bool profile = false; hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -522,7 +535,7 @@ int pass_f32(Index* ix, hipStream_t s, const float* qp, const float* qnorm, floa
             mp.keys = ix->w_pool.p; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
             mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl;
             mp.kk = kp; mp.out_keys = ix->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
-            mp.out_thr = nullptr; mp.ovf = d_ovf + q0;
+            mp.out_thr = nullptr; mp.ovf = d_ovf + q0; mp.summary = d_status + 1;
             vdb::launch_select(mp, nb, s);
         }
         vdb::RerankParams rp{};
@@ -596,7 +609,7 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         mp.keys = ix->w_pool.p; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
         mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl;
         mp.kk = kp; mp.out_keys = ix->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
-        mp.out_thr = nullptr; mp.ovf = d_ovf + q0;
+        mp.out_thr = nullptr; mp.ovf = d_ovf + q0; mp.summary = d_status + 1;
         vdb::launch_select(mp, nb, s);
 
         vdb::RerankParams rp{};
@@ -615,10 +628,13 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
 }
 
 // ------------------------------------------------------------------ the batched search
-int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, const uint64_t* d_idmask,
-                  size_t mask_bits, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
-                  hipStream_t user_stream) {
+// Part 1: checks, workspace, and the FIRST tier enqueued on the stream -- no host synchronisation unless the search is
+// one of the cases answered completely here (empty store, k = 0, k too large for the MFMA tiers).
+int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, const uint64_t* d_idmask,
+                 size_t mask_bits, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
+                 hipStream_t user_stream) {
     int rc;
+    ix->ctx.pending = false;
     if ((rc = set_device(ix))) return rc;
     if ((rc = flush(ix))) return rc;
     if (nq == 0) return VDB_OK;
@@ -663,8 +679,6 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
     if ((rc = ix->w_flags.ensure(4 + 2 * (size_t)nq32))) return rc;
     if (ix->h_flags_n < 4 + 2 * (size_t)nq32) {
         if (ix->h_flags) (void)hipHostFree(ix->h_flags);
-    if (ix->h_pairs) (void)hipHostFree(ix->h_pairs);
-    if (ix->h_pout) (void)hipHostFree(ix->h_pout);
         ix->h_flags = nullptr;
         ix->h_flags_n = 0;
         size_t want = 4 + 2 * (size_t)nq32 + 1024;
@@ -741,8 +755,29 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, (4 + 2 * (size_t)nq32) * 4, hipMemcpyDeviceToHost, s));
     ix->stats[10] = since();                       // host time until everything of the first tier is enqueued, ns
-    static const int spin_mode = getenv("VDB_SPIN") ? atoi(getenv("VDB_SPIN")) : 0;
-    if (spin_mode == 1) { while (hipStreamQuery(s) == hipErrorNotReady) { } }
+    Index::SearchCtx& c = ix->ctx;
+    c.pending = true; c.nq32 = nq32; c.kp = kp; c.kp16 = kp16; c.k = k; c.s = s; c.d_rowmask = d_rowmask;
+    c.d_out_ids = d_out_ids; c.d_out_dists = d_out_dists; c.d_out_counts = d_out_counts; c.t_entry = t_entry;
+    return VDB_OK;
+}
+
+// Part 2: wait for the first tier, read its flags, run the fallback tiers for the queries it could not certify.
+// *changed (may be null) tells whether outputs were rewritten after part 1's pass.
+int search_part2(Index* ix, int* changed) {
+    if (changed) *changed = 0;
+    Index::SearchCtx& c = ix->ctx;
+    if (!c.pending) return VDB_OK;
+    c.pending = false;
+    int rc;
+    const uint32_t nq32 = c.nq32, kp = c.kp, kp16 = c.kp16;
+    const size_t k = c.k;
+    hipStream_t s = c.s;
+    const uint32_t* d_rowmask = c.d_rowmask;
+    uint64_t* d_out_ids = c.d_out_ids; float* d_out_dists = c.d_out_dists; uint32_t* d_out_counts = c.d_out_counts;
+    const uint32_t n = ix->n_uploaded, ld = ix->ld;
+    uint32_t* d_status = ix->w_flags.p;
+    const auto t_entry = c.t_entry;
+    auto since = [&]() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_entry).count(); };
     HIP_TRY(hipStreamSynchronize(s));
     ix->stats[11] = since();                       // ... until the first tier's flags are on the host, ns
     uint32_t status = ix->h_flags[0];
@@ -757,6 +792,7 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
         if (cert && !ovf && !force_exact && !(kp16 && getenv("VDB_FORCE_TIER1"))) continue;
         todo.push_back(q);
     }
+    if (changed && !todo.empty()) *changed = 1;
     if (kp16 && !todo.empty()) {
         // ---- second tier: the uncertified queries as one compact block through the f32 MFMA pipeline
         const uint32_t nf = (uint32_t)todo.size(), nfp = round_up(nf, SUPER);
@@ -853,10 +889,18 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
         HIP_TRY(hipStreamSynchronize(s));
         st2 |= ix->h_flags[0];
     }
-    ix->status_dirty = st2 != 0;
+    ix->status_dirty = st2 != 0 || ix->stats[6] != 0 || ix->stats[2] != 0;      // status bits, or the summary word was set
     if (st2 & vdb::ST_NAN)
         return fail(VDB_ERR_NAN, "NaN distance (the reference panics here, flat_index.rs:62)");
     return VDB_OK;
+}
+
+int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, const uint64_t* d_idmask,
+                  size_t mask_bits, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
+                  hipStream_t user_stream) {
+    int rc = search_part1(ix, d_q, nq, dim, k, d_idmask, mask_bits, d_out_ids, d_out_dists, d_out_counts, user_stream);
+    if (rc) { ix->ctx.pending = false; return rc; }
+    return search_part2(ix, nullptr);
 }
 
 }  // namespace
@@ -925,6 +969,7 @@ void vdb_flat_destroy(vdb_flat_index* ix) {
     if (ix->h_pairs) (void)hipHostFree(ix->h_pairs);
     if (ix->h_pout) (void)hipHostFree(ix->h_pout);
     if (ix->ev0) { (void)hipEventDestroy(ix->ev0); (void)hipEventDestroy(ix->ev1); }
+    if (ix->ev_order) (void)hipEventDestroy(ix->ev_order);
     (void)hipStreamDestroy(ix->stream);
     delete ix;
 }
@@ -1111,6 +1156,44 @@ int vdb_flat_search_batch_device(vdb_flat_index* ix, const float* d_queries, siz
     std::lock_guard<std::mutex> g(ix->mu);
     return search_device(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts,
                          (hipStream_t)stream);
+}
+
+int vdb_flat_search_batch_device_begin(vdb_flat_index* ix, const float* d_queries, size_t nq, size_t dim, size_t k,
+                                       const uint64_t* d_id_mask, size_t mask_bits, uint64_t* d_out_ids,
+                                       float* d_out_dists, uint32_t* d_out_counts, int32_t* d_code, void* stream) {
+    if (!ix || (nq && (!d_queries || !d_out_counts || (k && (!d_out_ids || !d_out_dists)))))
+        return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    ix->mu.lock();
+    if (ix->begin_locked) { ix->mu.unlock(); return fail(VDB_ERR_INVALID_ARGUMENT, "a search is already pending on this handle"); }
+    int rc = search_part1(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts, (hipStream_t)stream);
+    if (rc == VDB_OK && d_code) {
+        hipStream_t s = stream ? (hipStream_t)stream : ix->stream;
+        if (ix->ctx.pending) vdb::launch_write_code(ix->w_flags.p, d_code, s);
+        else if (hipMemsetAsync(d_code, 0, 4, s) != hipSuccess) rc = fail(VDB_ERR_DEVICE, "hipMemsetAsync failed");
+    }
+    if (rc == VDB_OK && !stream) {
+        // the work went to the handle's own (non-blocking) stream: whatever the caller enqueues next on the null stream
+        // -- the exchange -- must wait for it
+        if (!ix->ev_order && hipEventCreateWithFlags(&ix->ev_order, hipEventDisableTiming) != hipSuccess) rc = fail(VDB_ERR_DEVICE, "hipEventCreate failed");
+        if (rc == VDB_OK && (hipEventRecord(ix->ev_order, ix->stream) != hipSuccess || hipStreamWaitEvent(nullptr, ix->ev_order, 0) != hipSuccess))
+            rc = fail(VDB_ERR_DEVICE, "stream ordering failed");
+    }
+    if (rc) {
+        if (ix->ctx.pending) (void)hipStreamSynchronize(ix->ctx.s);
+        ix->ctx.pending = false; ix->mu.unlock(); return rc;
+    }
+    ix->begin_locked = true;                                   // released by vdb_flat_search_batch_device_finish (same thread)
+    return VDB_OK;
+}
+
+int vdb_flat_search_batch_device_finish(vdb_flat_index* ix, int* changed) {
+    if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    if (!ix->begin_locked) return fail(VDB_ERR_INVALID_ARGUMENT, "no search pending on this handle");
+    int rc = search_part2(ix, changed);
+    ix->ctx.pending = false;
+    ix->begin_locked = false;
+    ix->mu.unlock();
+    return rc;
 }
 
 int vdb_flat_search_batch(vdb_flat_index* ix, const float* queries, size_t nq, size_t dim, const size_t* ks,

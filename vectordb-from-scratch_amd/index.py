@@ -220,6 +220,25 @@ class GpuFlatIndex(Index):
         if rc:
             _raise(rc)
 
+    def search_batch_device_begin(self, q_ptr, nq, dim, k, out_ids_ptr, out_dists_ptr, out_counts_ptr, code_ptr=0,
+                                  stream=0, mask_ptr=0, mask_bits=0):
+        """First tier enqueued, no host synchronisation; *code_ptr (device int32) = 0 or VDB_PENDING_HOST (100).
+        Must be followed by search_batch_device_finish() from the same thread."""
+        rc = self._L.vdb_flat_search_batch_device_begin(
+            self._h, ctypes.c_void_p(q_ptr), int(nq), int(dim), int(k), ctypes.c_void_p(mask_ptr or None),
+            int(mask_bits), ctypes.c_void_p(out_ids_ptr), ctypes.c_void_p(out_dists_ptr),
+            ctypes.c_void_p(out_counts_ptr), ctypes.c_void_p(code_ptr or None), ctypes.c_void_p(stream or None))
+        if rc:
+            _raise(rc)
+
+    def search_batch_device_finish(self):
+        """Waits, runs the fallback tiers where needed; returns True when outputs were rewritten."""
+        changed = ctypes.c_int(0)
+        rc = self._L.vdb_flat_search_batch_device_finish(self._h, ctypes.byref(changed))
+        if rc:
+            _raise(rc)
+        return bool(changed.value)
+
     def distances_batch(self, queries, id_lists):
         """Exact reference distances of query b to the stored ids id_lists[b] (HNSW candidate lists)."""
         qs = np.ascontiguousarray(queries, dtype=np.float32)

@@ -90,31 +90,13 @@ class ShardedSearcher:
         counts = pk[3 * B * k:3 * B * k + B]
         return pk, ids, dists, counts, words
 
-    def search_batch(self, queries, k):
-        code = 0
-        err = None
-        B = queries.shape[0]
-        if self.world > 1:
-            pk, ids, dists, counts, words = self._buffers(B, k, queries.device)
-            outs = (ids, dists, counts)
-        else:
-            outs = None
-        try:
-            res = self.local_search(queries, k, outs) if outs is not None else self.local_search(queries, k)
-            if outs is not None and res[0].data_ptr() != ids.data_ptr():      # a local search that ignores `outs`
-                ids.copy_(res[0]); dists.copy_(res[1]); counts.copy_(res[2].to(torch.int32))
-            elif outs is None:
-                ids, dists, counts = res
-        except VectorDbError as e:            # keep the collective call pattern identical on every rank
-            err, code = e, _ERR_CODE.get(type(e), 4)
-            if outs is None:
-                raise
-            ids.zero_(); dists.zero_(); counts.zero_()
-        if self.world == 1:
-            return ids, dists, counts
-        pk[words - 1] = code
+    PENDING_HOST = 100                     # VDB_PENDING_HOST: some rank's first tier left queries for the host to finish
+
+    def _exchange(self, pk, B, k, ids):
+        """ONE all-gather of the packed per-rank buffers + merge; returns (out, worst status) -- the only host sync."""
         dist.all_gather_into_tensor(self._gath, pk, group=self.group)
         g = self._gath.view(self.world, pk.numel())
+        words = B * (3 * k + 1) + 1
         if ids.is_cuda and self.merge is None:
             # merge straight out of the gathered buffer; the kernel also reduces the status words
             out_i = torch.empty((B, k), dtype=torch.int64, device=ids.device)
@@ -126,15 +108,50 @@ class ShardedSearcher:
                 ctypes.c_void_p(out_c.data_ptr() + 4 * B), ctypes.c_void_p(torch.cuda.current_stream(ids.device).cuda_stream))
             if rc:
                 raise IndexError_(_ffi.last_error()[0])
-            out = (out_i, out_d, out_c[:B])
-            worst = int(out_c[B].item())                  # the ONE host sync of the exchange
-        else:
-            g_ids = g[:, :2 * B * k].contiguous().view(torch.int64).view(self.world, B, k)
-            g_d = g[:, 2 * B * k:3 * B * k].contiguous().view(torch.float32).view(self.world, B, k)
-            g_cnt = g[:, 3 * B * k:3 * B * k + B].contiguous()
-            merge = self.merge or merge_topk_torch
-            out = merge(g_ids, g_d, g_cnt, k)
-            worst = int(g[:, words - 1].max().item())
+            return (out_i, out_d, out_c[:B]), int(out_c[B].item())                   # the ONE host sync of the exchange
+        g_ids = g[:, :2 * B * k].contiguous().view(torch.int64).view(self.world, B, k)
+        g_d = g[:, 2 * B * k:3 * B * k].contiguous().view(torch.float32).view(self.world, B, k)
+        g_cnt = g[:, 3 * B * k:3 * B * k + B].contiguous()
+        merge = self.merge or merge_topk_torch
+        return merge(g_ids, g_d, g_cnt, k), int(g[:, words - 1].max().item())
+
+    def search_batch(self, queries, k):
+        code = 0
+        err = None
+        B = queries.shape[0]
+        if self.world == 1:
+            return self.local_search(queries, k)
+        pk, ids, dists, counts, words = self._buffers(B, k, queries.device)
+        outs = (ids, dists, counts)
+        # Two-half local search when the index offers it: the first tier is only ENQUEUED, its "needs the host" word lands
+        # in the packed buffer on the device, and the exchange is enqueued right behind it -- one host sync per batch.
+        begin = getattr(self.local_search, "begin", None)
+        pending = False
+        try:
+            if begin is not None and queries.is_cuda:
+                begin(queries, k, outs, pk[words - 1:words].data_ptr())
+                pending = True
+            else:
+                res = self.local_search(queries, k, outs)
+                if res[0].data_ptr() != ids.data_ptr():      # a local search that ignores `outs`
+                    ids.copy_(res[0]); dists.copy_(res[1]); counts.copy_(res[2].to(torch.int32))
+        except VectorDbError as e:            # keep the collective call pattern identical on every rank
+            err, code = e, _ERR_CODE.get(type(e), 4)
+            ids.zero_(); dists.zero_(); counts.zero_()
+        if not pending:
+            pk[words - 1] = code
+        out, worst = self._exchange(pk, B, k, ids)
+        if pending:
+            try:
+                changed = self.local_search.finish()          # fallback tiers for this rank's uncertified queries, errors
+            except VectorDbError as e:
+                err, code, changed = e, _ERR_CODE.get(type(e), 4), True
+                ids.zero_(); dists.zero_(); counts.zero_()
+            if worst == self.PENDING_HOST:                    # some rank rewrote its partial results: exchange again
+                pk[words - 1] = code
+                out, worst = self._exchange(pk, B, k, ids)
+            elif err is not None:
+                worst = max(worst, code)
         if worst:
             if err:
                 raise err
@@ -166,4 +183,14 @@ def gpu_local_search(index, mask_ptr=0, mask_bits=0, reuse_outputs=False):
                                   stream=torch.cuda.current_stream(dev).cuda_stream, mask_ptr=mask_ptr,
                                   mask_bits=mask_bits)
         return ids, dists, counts
+
+    def begin(queries, k, outs, code_ptr):
+        B, d = queries.shape
+        ids, dists, counts = outs
+        index.search_batch_device_begin(queries.data_ptr(), B, d, k, ids.data_ptr(), dists.data_ptr(), counts.data_ptr(),
+                                        code_ptr=code_ptr, stream=torch.cuda.current_stream(queries.device).cuda_stream,
+                                        mask_ptr=mask_ptr, mask_bits=mask_bits)
+
+    run.begin = begin
+    run.finish = index.search_batch_device_finish
     return run
