@@ -140,12 +140,20 @@ class ShardedSearcher:
             ids.zero_(); dists.zero_(); counts.zero_()
         if not pending:
             pk[words - 1] = code
-        out, worst = self._exchange(pk, B, k, ids)
+        try:
+            out, worst = self._exchange(pk, B, k, ids)
+        except BaseException:
+            if pending:                                       # never leave the handle locked behind a failed collective
+                try:
+                    self.local_search.finish()
+                except VectorDbError:
+                    pass
+            raise
         if pending:
             try:
-                changed = self.local_search.finish()          # fallback tiers for this rank's uncertified queries, errors
+                self.local_search.finish()                    # fallback tiers for this rank's uncertified queries, errors
             except VectorDbError as e:
-                err, code, changed = e, _ERR_CODE.get(type(e), 4), True
+                err, code = e, _ERR_CODE.get(type(e), 4)
                 ids.zero_(); dists.zero_(); counts.zero_()
             if worst == self.PENDING_HOST:                    # some rank rewrote its partial results: exchange again
                 pk[words - 1] = code
