@@ -648,20 +648,35 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
         // ---- bitonic sort of the first P >= processed (dist, id) pairs, ascending; unused slots hold the maximum
         uint32_t P = 32;
         while (P < processed) P <<= 1;
-        for (uint32_t size = 2; size <= P; size <<= 1) {
-            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-                if (tid < P / 2) {
-                    uint32_t lo = 2 * tid - (tid & (stride - 1));
-                    uint32_t hi = lo + stride;
-                    bool up = ((lo & size) == 0);
-                    uint32_t da = sDist[lo], db = sDist[hi];
-                    uint64_t ia = sId[lo], ib = sId[hi];
-                    bool gt = da > db || (da == db && ia > ib);
-                    if (gt == up) { sDist[lo] = db; sDist[hi] = da; sId[lo] = ib; sId[hi] = ia; }
-                }
-                __syncthreads();
-            }
+#define VDB_CEX()                                                                                      \
+        {                                                                                              \
+            uint32_t lo = 2 * tid - (tid & (stride - 1));                                              \
+            uint32_t hi = lo + stride;                                                                 \
+            bool up = ((lo & size) == 0);                                                              \
+            uint32_t da = sDist[lo], db = sDist[hi];                                                   \
+            uint64_t ia = sId[lo], ib = sId[hi];                                                       \
+            bool gt = da > db || (da == db && ia > ib);                                                \
+            if (gt == up) { sDist[lo] = db; sDist[hi] = da; sId[lo] = ib; sId[hi] = ia; }              \
         }
+        if (P <= 128) {
+            // at most 64 compare-exchange pairs: ONE wave does the whole network.  LDS operations of a wave execute in
+            // order, so the steps need no workgroup barrier between them -- only the compiler must keep their order.
+            if (wv == 0)
+                for (uint32_t size = 2; size <= P; size <<= 1)
+                    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                        if (tid < P / 2) VDB_CEX()
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+            __syncthreads();
+        } else {
+            for (uint32_t size = 2; size <= P; size <<= 1)
+                for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                    if (tid < P / 2) VDB_CEX()
+                    __syncthreads();
+                }
+        }
+#undef VDB_CEX
         // number of real candidates so far (ineligible ones sorted to the end with id ~0)
         if (tid < RR_MAX) {
             unsigned long long b0 = __ballot(tid < processed && sId[tid] != ~0ull);
