@@ -123,11 +123,17 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
     }
     const uint32_t total = ntiles * KS;
     const uint32_t last_row = p.n_rows - 1;
-    // sample index -> device row.  Scattered: (j * n) >> shift.  Block mode (sample_block != 0): the sample is made of
-    // 256-row tiles of CONTIGUOUS rows spaced sample_block rows apart, i.e. the access pattern of the filter pass.
+    // sample index -> device row.  The S sample positions are spread evenly over the rows ((pos * n) >> shift), and
+    // CONSECUTIVE positions go to DIFFERENT tiles (index j = tile*256 + tile-row sits at position tile-row*tiles + tile):
+    // when near neighbours are stored next to each other (data ordered by cluster) their sample rows then land in
+    // different groups, each contributes its own group minimum, and the threshold stays as tight as on shuffled data
+    // (with consecutive positions in one tile a 500-row cluster was represented by 4 minima, the threshold came from far
+    // rows and thousands of keys overflowed the pools).  Block mode (sample_block != 0, diagnostics): tiles of
+    // contiguous rows.
     auto sample_row_of = [&](uint32_t j) -> uint32_t {
         if (p.sample_block) return (j >> 8) * p.sample_block + (j & 255u);
-        return (uint32_t)(((uint64_t)j * p.n_rows) >> p.sample_shift);
+        const uint32_t pos = (j & 255u) * (p.n_sample >> 8) + (j >> 8);
+        return (uint32_t)(((uint64_t)pos * p.n_rows) >> p.sample_shift);
     };
     const char* __restrict__ rows_b = reinterpret_cast<const char*>(p.rows);
     const char* __restrict__ bbase = reinterpret_cast<const char*>(p.qb);
