@@ -190,6 +190,8 @@ int vdb_flat_last_stats(const vdb_flat_index *h, uint64_t out[8]);
  *  [8] 1 when the bf16 screening tier answered the batch first, 0 when only the f32 MFMA tier ran
  *  [9] queries the screening tier could not certify and handed to the f32 MFMA tier
  *  [10] [11] [12] host clock of the call, ns: first tier enqueued / its flags on the host / return
+ *  [13] queries answered by the re-threshold pass (a second screening pass whose thresholds are the score cuts that the
+ *       k-th exact distances of the first pass imply; every key under the cut is re-ranked)
  * With the screening tier on, [4] [5] [7] describe ITS sample, k' and kernel time. */
 int vdb_flat_last_stats_ex(const vdb_flat_index *h, uint64_t *out, size_t n);
 

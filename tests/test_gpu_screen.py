@@ -147,6 +147,24 @@ def test_near_duplicates_within_bf16_resolution(vdb):
         check_oracle(metric, rows, q, 10, a, range(3))
 
 
+def test_rethreshold_pass_answers_what_the_depth_limit_could_not(vdb):
+    """600 rows inside the bf16 error bound of each other: the first pass re-ranks 256 candidates without a certificate,
+    but its k-th exact distance implies a score cut; the re-threshold pass filters with that cut, re-ranks EVERY key
+    under it and is exact by construction -- no f32 tier, no exact scan."""
+    rng = np.random.default_rng(28)
+    n, d = 120000, 96
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    centre = rng.standard_normal(d).astype(np.float32) * 2.0
+    rows[40000:40600] = centre + 1e-3 * rng.standard_normal((600, d)).astype(np.float32)
+    q = (centre + 1e-4 * rng.standard_normal((5, d))).astype(np.float32)
+    for metric in (0, 1, 2):
+        ix = make_index(vdb, metric, rows)
+        a, st, b = both_tiers(ix, q, 10)
+        assert st["bf16_screen"] == 1 and st["rethreshold_queries"] == 5 and st["f32_tier_queries"] == 0 and st["exact_queries"] == 0, st
+        assert same(a, b)
+        check_oracle(metric, rows, q, 10, a, range(5))
+
+
 def test_clustered_row_order_stays_on_the_screen_tier(vdb):
     """All near neighbours sit in ONE row range (data stored cluster by cluster): nearly every key that passes the
     threshold lands in one workgroup's private sub-pools.  They are sized for that (4 x 256 slots per query and

@@ -50,7 +50,7 @@ def main():
     rng = np.random.default_rng(a.seed)
     kinds = ["uniform", "gauss", "unit", "clustered", "dups", "scales"]
     t0 = time.time()
-    tiers = {"screen": 0, "f32q": 0, "exact": 0, "ovf": 0}
+    tiers = {"screen": 0, "rethr": 0, "f32q": 0, "exact": 0, "ovf": 0}
     for case in range(a.cases):
         n = int(rng.integers(16385, a.max_rows))
         d = int(rng.choice([1, 3, 17, 32, 33, 64, 100, 128, 200, 384, 768]))
@@ -102,8 +102,8 @@ def main():
             oi, od = oracle.flat_search(metric, rows, queries[b], k, ids=ids, live=elig)
             gi, gd, gc = a1
             ok &= bool(gc[b] == len(oi) and np.array_equal(gi[b, :gc[b]], oi) and np.array_equal(gd[b, :gc[b]].view(np.uint32), od.view(np.uint32)))
-        tiers["screen"] += st["bf16_screen"]; tiers["f32q"] += st["f32_tier_queries"]; tiers["exact"] += st["exact_queries"]; tiers["ovf"] += st["pool_overflows"]
-        print(("ok   " if ok else "FAIL ") + desc + f"  [screen={st['bf16_screen']} f32q={st['f32_tier_queries']} exact={st['exact_queries']} ovf={st['pool_overflows']}]", flush=True)
+        tiers["screen"] += st["bf16_screen"]; tiers["rethr"] += st["rethreshold_queries"]; tiers["f32q"] += st["f32_tier_queries"]; tiers["exact"] += st["exact_queries"]; tiers["ovf"] += st["pool_overflows"]
+        print(("ok   " if ok else "FAIL ") + desc + f"  [screen={st['bf16_screen']} rethr={st['rethreshold_queries']} f32q={st['f32_tier_queries']} exact={st['exact_queries']} ovf={st['pool_overflows']}]", flush=True)
         if not ok:
             sys.exit(1)
         del ix

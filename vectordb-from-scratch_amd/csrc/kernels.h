@@ -118,6 +118,7 @@ struct SelectParams {
     float* out_thr;                                    // may be null: score of the kk-th key, +inf if fewer
     uint32_t* ovf;                                     // may be null: set when counts[q] > cap
     uint32_t* summary;                                 // may be null: OR-ed with 2 whenever an overflow flag is set
+    uint32_t flag_truncation;                          // 1: more valid keys than kk also sets ovf[q] (the caller needs ALL of them)
     const uint64_t* lo_excl;                           // may be null: only keys > lo_excl[q] take part (chunked large k)
     uint64_t* out_last;                                // may be null: largest selected key per query (unchanged if none)
 };
@@ -176,6 +177,11 @@ void launch_scatter_results(const uint64_t* ids, const float* dists, const uint3
                             uint32_t n, uint32_t k, uint64_t* out_ids, float* out_dists, uint32_t* out_counts,
                             hipStream_t s);
 
+// the same for an explicit (source, destination) list
+void launch_scatter_results_list(const uint64_t* ids, const float* dists, const uint32_t* counts, const uint32_t* src,
+                                 const uint32_t* dst, uint32_t n, uint32_t k, uint64_t* out_ids, float* out_dists,
+                                 uint32_t* out_counts, hipStream_t s);
+
 // ---------------------------------------------------------------- exact re-rank + certification
 struct RerankParams {
     const float* rows; uint32_t ld; uint32_t dim; uint32_t n_rows;
@@ -186,6 +192,8 @@ struct RerankParams {
     const uint64_t* cand; uint32_t cand_stride; const uint32_t* cand_cnt; uint32_t kp;   // kp <= 256 candidates, sorted by score
     uint32_t kp_first, kp_step;                        // adaptive depth: re-rank kp_first, then kp_step more per round (0: kp at once)
     uint32_t* depth;                                   // may be null: candidates re-ranked per query (diagnostics)
+    float* thr_next;                                   // may be null: for an UNCERTIFIED query the score cut above which no row can
+                                                       // enter the top k (from the k-th exact distance found so far); NaN: no cut known
     int metric;
     uint32_t k;                                        // results wanted per query
     float eps_coef; const uint32_t* nd2max_bits;       // certification bound inputs (max row norm^2, f32 bits)
@@ -200,6 +208,9 @@ struct RerankParams {
     uint32_t lds_row_stride, lds_chunk;                // filled by launch_rerank
 };
 void launch_rerank(const RerankParams& p, uint32_t nq, hipStream_t s);
+// exhaustive variant: EVERY candidate of the list (up to cand_stride, any order) is re-ranked, the best k are kept;
+// cert[q] = 1 unless the list was truncated upstream (the caller's overflow flag) or a NaN score was seen
+void launch_rerank_all(const RerankParams& p, uint32_t nq, hipStream_t s);
 
 // ---------------------------------------------------------------- exact scan (fallback, any k)
 struct ExactScanParams {

@@ -404,6 +404,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
     __syncthreads();
     const uint32_t nvalid = sValid;
     const uint32_t kk = nvalid < p.kk ? nvalid : p.kk;
+    if (p.flag_truncation && nvalid > p.kk && p.ovf && tid == 0) { p.ovf[q] = 1u; if (p.summary) atomicOr(p.summary, 2u); }
     uint64_t* out = p.out_keys + (size_t)q * p.out_stride;
     if (kk == 0) {
         for (uint32_t i = tid; i < p.kk; i += SEL_THREADS) out[i] = EMPTY_KEY;
@@ -573,6 +574,31 @@ __device__ __forceinline__ bool cert_test(const RerankParams& p, uint32_t q, flo
     return ek * ek < (double)T + qn * qn - eps * (s * s + ek * ek);
 }
 
+// The inverse of cert_test: the smallest score T* such that cert_test(T) holds for every T > T*.  Every row whose
+// ranking score exceeds it is PROVEN to lie beyond the k-th exact distance ek, so a filter pass with T* (rounded up) as
+// its threshold keeps every row that can still matter (the "re-threshold" pass of vdb_flat.cpp).
+__device__ __forceinline__ float score_cut(const RerankParams& p, uint32_t q, double ek, double qn) {
+    const double eps = (double)p.eps_coef;
+    const double ndmax = sqrt((double)__uint_as_float(p.nd2max_bits[0]));
+    double E = 0.0, Ec = 0.0;
+    if (p.qerr) {
+        const double eq = (double)p.qerr[q];
+        const double emax = sqrt((double)__uint_as_float(p.nd2max_bits[2]));
+        const double rmax = sqrt((double)__uint_as_float(p.nd2max_bits[3]));
+        const double cacc = (double)p.c_acc;
+        E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
+        Ec = 1.01 * (eq / qn + 1.004 * rmax) + cacc;
+    }
+    double t;
+    if (p.metric == DOT) t = ek + E + eps * qn * ndmax;
+    else if (p.metric == COSINE) t = (ek - 1.0 + Ec + eps) * qn;
+    else { const double s = qn + ndmax; t = ek * ek - qn * qn + 2.0 * E + eps * (s * s + ek * ek); }
+    t += fabs(t) * 1e-6 + 1e-30;                                // slack: looser is safe
+    float f = (float)t;
+    if ((double)f < t) f = __uint_as_float(__float_as_uint(f) + (f >= 0.0f ? 1u : (uint32_t)-1));   // round towards +inf
+    return f;
+}
+
 typedef __attribute__((address_space(3))) void* rr_lds_t;
 typedef const __attribute__((address_space(1))) void* rr_glb_t;
 constexpr uint32_t RR_MAX = 512;        // candidates per query at most (= RR_THREADS: one thread per candidate)
@@ -619,6 +645,8 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
     uint32_t target = cnt < p.kp_first ? cnt : p.kp_first;
     uint32_t nout = 0;
     uint32_t cert = 1;
+    bool cut_ok = false;                                          // a k-th exact distance exists and no NaN / ineligible candidate was seen
+    double cut_ek = 0.0;
     while (true) {
         // ---- exact distances of candidates [processed, target)
         for (uint32_t c0 = processed; c0 < target; c0 += chunk) {
@@ -692,6 +720,7 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
         const bool can_test = clean && nout == p.k && nout > 0;
         const double ek = can_test ? (double)ordered_to_f32(sDist[nout - 1]) : 0.0;
         const double qn = (double)qn_f;
+        cut_ok = can_test; cut_ek = ek;
         if (processed < cnt) {
             // every candidate not yet re-ranked tests "would the result be certified if the re-rank stopped just
             // before me": the first one that says yes is where the next round ends (ek can only shrink meanwhile)
@@ -735,9 +764,122 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
         if (sAnyNan) atomicOr(p.status, ST_NAN);
         p.cert[q] = cert;
         if (!cert) atomicOr(p.status + 1, 1u);             // summary word of the status block: some query needs the next tier
+        if (p.thr_next) {
+            float cut = __uint_as_float(0x7fc00000u);             // NaN: no cut known
+            if (!cert && cut_ok) cut = score_cut(p, q, cut_ek, (double)qn_f);
+            p.thr_next[q] = cut;
+        }
         if (p.depth) p.depth[q] = processed;
     }
 }
+// ---------------------------------------------------------------------------------------------
+// Exhaustive re-rank (the re-threshold pass): EVERY key of the query's list is re-ranked in the reference's
+// arithmetic, chunk by chunk; slots [0, k) of the sort area always hold the best k seen so far, each chunk is sorted
+// in behind them and the area cut back to k.  The list is complete by construction (every row whose score is at or
+// below the cut passed the filter), so the result is exact unless the list was truncated upstream.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RR_THREADS) void rerank_all_kernel(RerankParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sRows[];
+    constexpr uint32_t AREA = 256;                                // k <= 112 plus a chunk of <= 64
+    __shared__ uint32_t sDist[AREA];
+    __shared__ uint64_t sId[AREA];
+    __shared__ uint32_t sRowIdx[64];
+    __shared__ uint32_t sAnyNan, sNanKey;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t cnt = p.cand_cnt[q] < p.cand_stride ? p.cand_cnt[q] : p.cand_stride;
+    const uint64_t* cand = p.cand + (size_t)q * p.cand_stride;
+    if (tid == 0) { sAnyNan = 0; sNanKey = 0; }
+    if (tid < AREA) { sDist[tid] = 0xffffffffu; sId[tid] = ~0ull; }
+    const uint32_t dimp = (p.dim + 3) & ~3u;
+    const uint32_t ldp = p.lds_row_stride;
+    uint32_t chunk = p.lds_chunk < 64 ? p.lds_chunk : 64;
+    if (chunk > AREA - p.k) chunk = AREA - p.k;
+    float* sQ = sRows;
+    float* sR = sRows + ldp;
+    const float* gq = p.qp + (size_t)q * p.ld;
+    for (uint32_t i = tid * 4; i < dimp; i += RR_THREADS * 4) *reinterpret_cast<float4*>(sQ + i) = *reinterpret_cast<const float4*>(gq + i);
+    __syncthreads();
+    const uint32_t vpr = dimp / 4, bpr = (vpr + 63) / 64, nwaves = RR_THREADS / 64;
+    const float qn_f = p.qnorm[q];
+    for (uint32_t c0 = 0; c0 < cnt; c0 += chunk) {
+        const uint32_t nthis = (cnt - c0 < chunk) ? cnt - c0 : chunk;
+        if (tid < nthis) {
+            const uint64_t key = cand[c0 + tid];
+            uint32_t row = (uint32_t)key;
+            if ((uint32_t)(key >> 32) == 0u) sNanKey = 1u;
+            const bool ok = row < p.n_rows && (p.rowmask ? ((p.rowmask[row >> 5] >> (row & 31)) & 1u) : true);
+            sRowIdx[tid] = ok ? row : 0xffffffffu;
+        }
+        __syncthreads();
+        for (uint32_t u = wv; u < nthis * bpr; u += nwaves) {
+            const uint32_t r = u / bpr, b = u % bpr, c4 = b * 64 + lane;
+            const uint32_t row = sRowIdx[r];
+            if (row != 0xffffffffu && c4 < vpr)
+                __builtin_amdgcn_global_load_lds((rr_glb_t)(p.rows + (size_t)row * p.ld + 4 * c4),
+                                                 (rr_lds_t)(sR + (size_t)r * ldp + 256 * b), 16, 0, 0);
+        }
+        __syncthreads();
+        if (tid < nthis) {
+            const uint32_t row = sRowIdx[tid];
+            uint32_t od = 0xffffffffu;
+            uint64_t id = ~0ull;
+            if (row != 0xffffffffu) {
+                const float dist = exact_distance(p.metric, sQ, sR + (size_t)tid * ldp, p.dim, qn_f, p.nd[row]);
+                if (dist != dist) sAnyNan = 1u;
+                od = f32_to_ordered(dist);
+                id = p.row_ids[row];
+            }
+            sDist[p.k + tid] = od;
+            sId[p.k + tid] = id;
+        }
+        __syncthreads();
+        for (uint32_t size = 2; size <= AREA; size <<= 1)
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                if (tid < AREA / 2) {
+                    uint32_t lo = 2 * tid - (tid & (stride - 1));
+                    uint32_t hi = lo + stride;
+                    bool up = ((lo & size) == 0);
+                    uint32_t da = sDist[lo], db = sDist[hi];
+                    uint64_t ia = sId[lo], ib = sId[hi];
+                    bool gt = da > db || (da == db && ia > ib);
+                    if (gt == up) { sDist[lo] = db; sDist[hi] = da; sId[lo] = ib; sId[hi] = ia; }
+                }
+                __syncthreads();
+            }
+        if (tid >= p.k && tid < AREA) { sDist[tid] = 0xffffffffu; sId[tid] = ~0ull; }      // keep the best k only
+        __syncthreads();
+    }
+    uint32_t nout = 0;
+    {
+        __shared__ uint32_t sCnt[RR_THREADS / 64];
+        const unsigned long long b0 = __ballot(tid < p.k && sId[tid < AREA ? tid : 0] != ~0ull);
+        if (lane == 0) sCnt[wv] = (uint32_t)__popcll(b0);
+        __syncthreads();
+        for (uint32_t w8 = 0; w8 < RR_THREADS / 64; ++w8) nout += sCnt[w8];
+    }
+    if (tid < p.k) {
+        size_t o = (size_t)q * p.out_stride + tid;
+        if (tid < nout) { p.out_ids[o] = sId[tid]; p.out_dists[o] = ordered_to_f32(sDist[tid]); }
+        else { p.out_ids[o] = ~0ull; p.out_dists[o] = __uint_as_float(0x7fc00000u); }
+    }
+    if (tid == 0) {
+        p.out_counts[q] = nout;
+        if (sAnyNan) atomicOr(p.status, ST_NAN);
+        p.cert[q] = sNanKey ? 0u : 1u;                           // (a truncated list is flagged by the select: overflow)
+    }
+}
+void launch_rerank_all(const RerankParams& p, uint32_t nq, hipStream_t s) {
+    if (!nq) return;
+    RerankParams q = p;
+    uint32_t dimp = (p.dim + 3) & ~3u;
+    q.lds_row_stride = dimp + ((dimp % 8 == 0) ? 4 : 0);
+    uint32_t chunk = (uint32_t)std::min<size_t>(64, (150 * 1024) / ((size_t)q.lds_row_stride * 4));
+    chunk = chunk > 1 ? chunk - 1 : 1;
+    q.lds_chunk = chunk;
+    size_t lds = (size_t)(chunk + 1) * q.lds_row_stride * 4;
+    hipLaunchKernelGGL(rerank_all_kernel, dim3(nq), dim3(RR_THREADS), lds, s, q);
+}
+
 void launch_rerank(const RerankParams& p, uint32_t nq, hipStream_t s) {
     if (!nq) return;
     // LDS plan: query row + `chunk` candidate rows of padded stride (chunk = largest power of two that fits)
@@ -791,6 +933,24 @@ void launch_scatter_results(const uint64_t* ids, const float* dists, const uint3
                             hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(scatter_results_kernel, dim3(n), dim3(128), 0, s, ids, dists, counts, qidx, k, out_ids, out_dists,
+                       out_counts);
+}
+
+__global__ __launch_bounds__(128) void scatter_results_list_kernel(const uint64_t* ids, const float* dists, const uint32_t* counts,
+                                                                   const uint32_t* src, const uint32_t* dst, uint32_t k,
+                                                                   uint64_t* out_ids, float* out_dists, uint32_t* out_counts) {
+    const uint32_t j = src[blockIdx.x], q = dst[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        out_ids[(size_t)q * k + i] = ids[(size_t)j * k + i];
+        out_dists[(size_t)q * k + i] = dists[(size_t)j * k + i];
+    }
+    if (threadIdx.x == 0) out_counts[q] = counts[j];
+}
+void launch_scatter_results_list(const uint64_t* ids, const float* dists, const uint32_t* counts, const uint32_t* src,
+                                 const uint32_t* dst, uint32_t n, uint32_t k, uint64_t* out_ids, float* out_dists,
+                                 uint32_t* out_counts, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(scatter_results_list_kernel, dim3(n), dim3(128), 0, s, ids, dists, counts, src, dst, k, out_ids, out_dists,
                        out_counts);
 }
 

@@ -128,8 +128,9 @@ struct vdb_flat_index {
     DevBuf<uint32_t> w_cnt, w_rowmask, w_flags, w_outc, w_subcnt;
     DevBuf<uint16_t> w_qb;                                  // bf16 copy of the padded queries (screening tier)
     // compact block of the queries the screening tier could not certify (re-run by the f32 tier)
-    DevBuf<float> w2_qp, w2_qnorm, w2_thr, w2_outd;
-    DevBuf<uint64_t> w2_outi;
+    DevBuf<float> w2_qp, w2_qnorm, w2_thr, w2_outd, w2_qerr;
+    DevBuf<uint64_t> w2_outi, w2_cand;
+    DevBuf<uint16_t> w2_qb;
     DevBuf<uint32_t> w2_outc, w2_flags, w2_qidx;
     uint32_t* h_flags = nullptr; size_t h_flags_n = 0;
     bool status_dirty = true; uint32_t* status_buf = nullptr;   // device status block known to be zero?
@@ -557,7 +558,7 @@ int pass_f32(Index* ix, hipStream_t s, const float* qp, const float* qnorm, floa
 // keys -> exact re-rank, certified with the bf16 error bound.  Queries come from ix->w_qp / w_qb / w_qnorm.
 int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& pl, const uint32_t* d_rowmask,
               uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, uint32_t* d_cert, uint32_t* d_ovf,
-              uint32_t* d_status) {
+              uint32_t* d_status, float* d_thr_next) {
     int rc;
     const uint32_t n = ix->n_uploaded, ld = ix->ld;
     const uint32_t S = pl.S, kp = pl.kp, KT = pl.kt;
@@ -622,12 +623,96 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         rp.thr = ix->w_thr.p + q0;
         rp.qerr = ix->w_qerr.p + q0; rp.c_acc = c_acc_bf16(ix);
         rp.kp_first = round_up((uint32_t)k + 38u, 16u); rp.kp_step = 32;
+        rp.thr_next = d_thr_next ? d_thr_next + q0 : nullptr;
         vdb::launch_rerank(rp, nb, s);
     }
     return VDB_OK;
 }
 
 // ------------------------------------------------------------------ the batched search
+// ------------------------------------------------------------------ tier 0b: the re-threshold pass
+// For queries the screening tier re-ranked to its depth limit without a certificate, the k-th exact distance found so
+// far still bounds the answer: rerank_kernel turned it into a score cut above which no row can enter the top k.  The
+// queries are gathered into a compact block, the HBM-bound filter pass runs once more with those cuts as thresholds,
+// and EVERY key that passes (up to 2048 per query) is re-ranked exactly.  Exact by construction; a query whose list does
+// not fit (pool overflow, more than 2048 keys) keeps its flag and goes on to the next tier.
+// todo: batch indices; cuts: their score cuts.  On return flags2 (host) holds cert / overflow per compact query.
+int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo, const std::vector<float>& cuts, size_t k,
+                     const uint32_t* d_rowmask, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
+                     uint32_t* d_status, std::vector<uint32_t>& flags2) {
+    int rc;
+    const uint32_t n = ix->n_uploaded, ld = ix->ld;
+    const uint32_t nf = (uint32_t)todo.size(), nfp = round_up(nf, SUPER);
+    constexpr uint32_t KMAX = 2048;                              // keys re-ranked per query at most (select capacity)
+    const uint32_t capl = 256;
+    const uint32_t n_wg = std::min<uint32_t>((uint32_t)ix->n_cu, (n + vdb::fused_bf16_tile_rows() - 1) / vdb::fused_bf16_tile_rows());
+    const uint32_t n_sub = vdb::fused_bf16_subpools_per_query(n_wg);
+    if ((rc = ix->w2_qp.ensure((size_t)nfp * ld))) return rc;
+    if ((rc = ix->w2_qnorm.ensure(nfp))) return rc;
+    if ((rc = ix->w2_thr.ensure(nfp))) return rc;
+    if ((rc = ix->w2_qerr.ensure(nfp))) return rc;
+    if ((rc = ix->w2_qb.ensure((size_t)nfp * ld))) return rc;
+    if ((rc = ix->w2_outi.ensure((size_t)nf * k))) return rc;
+    if ((rc = ix->w2_outd.ensure((size_t)nf * k))) return rc;
+    if ((rc = ix->w2_outc.ensure(nf))) return rc;
+    if ((rc = ix->w2_flags.ensure(2 * (size_t)nf))) return rc;
+    if ((rc = ix->w2_qidx.ensure(nf))) return rc;
+    if ((rc = ix->w2_cand.ensure((size_t)SUPER * KMAX))) return rc;
+    if ((rc = ix->w_pool.ensure((size_t)SUPER * n_sub * capl))) return rc;
+    if ((rc = ix->w_subcnt.ensure((size_t)SUPER * n_sub))) return rc;
+    uint32_t* d_cert2 = ix->w2_flags.p;
+    uint32_t* d_ovf2 = ix->w2_flags.p + nf;
+    HIP_TRY(hipMemcpyAsync(ix->w2_qidx.p, todo.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
+    vdb::launch_gather_queries(ix->w_qp.p, ix->w_qnorm.p, ld, ix->w2_qidx.p, nf, nfp, ix->w2_qp.p, ix->w2_qnorm.p, ix->w2_thr.p, s);
+    // bf16 image, |q - bf16(q)| and zeroed flags of the compact block (the rows are already padded: dim = ld)
+    vdb::QueryPrepParams qp{ix->w2_qp.p, ld, nf, ix->w2_qp.p, ld, nfp, ix->w2_qnorm.p, ix->w2_thr.p, vdb::EUCLID, d_status,
+                            ix->w2_qb.p, ix->w2_qerr.p, d_cert2, d_ovf2};
+    vdb::launch_query_prep(qp, s);
+    HIP_TRY(hipMemcpyAsync(ix->w2_thr.p, cuts.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));   // padding queries keep -inf
+    uint32_t* d_cand_cnt = ix->w_cnt.p + 2 * SUPER;
+    for (uint32_t q0 = 0; q0 < nf; q0 += SUPER) {
+        const uint32_t nb = std::min(SUPER, nf - q0);
+        vdb::FusedBf16Params fp{};
+        fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w2_qb.p + (size_t)q0 * ld;
+        fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
+        fp.thr = ix->w2_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
+        vdb::launch_fused_bf16(fp, s);
+        ix->stats[3] += n;
+        vdb::SelectParams mp{};
+        mp.keys = ix->w_pool.p; mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl;
+        mp.kk = KMAX; mp.out_keys = ix->w2_cand.p; mp.out_stride = KMAX; mp.out_cnt = d_cand_cnt;
+        mp.ovf = d_ovf2 + q0; mp.summary = nullptr; mp.flag_truncation = 1;
+        vdb::launch_select(mp, nb, s);
+        vdb::RerankParams rp{};
+        rp.rows = ix->d_rows; rp.ld = ld; rp.dim = ix->dim; rp.n_rows = n;
+        rp.qp = ix->w2_qp.p + (size_t)q0 * ld; rp.qnorm = ix->w2_qnorm.p + q0; rp.nd = ix->d_nd; rp.row_ids = ix->d_row_ids;
+        rp.rowmask = d_rowmask; rp.cand = ix->w2_cand.p; rp.cand_stride = KMAX; rp.cand_cnt = d_cand_cnt; rp.kp = KMAX;
+        rp.metric = ix->metric; rp.k = (uint32_t)k; rp.nd2max_bits = ix->d_scalars;
+        rp.out_ids = ix->w2_outi.p + (size_t)q0 * k; rp.out_dists = ix->w2_outd.p + (size_t)q0 * k;
+        rp.out_counts = ix->w2_outc.p + q0; rp.out_stride = (uint32_t)k; rp.cert = d_cert2 + q0; rp.status = d_status;
+        vdb::launch_rerank_all(rp, nb, s);
+    }
+    HIP_TRY(hipGetLastError());
+    flags2.assign(2 * (size_t)nf, 0u);
+    HIP_TRY(hipMemcpyAsync(flags2.data(), ix->w2_flags.p, 2 * (size_t)nf * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    // only the queries this pass answered completely are written back
+    std::vector<uint32_t> good;
+    for (uint32_t j = 0; j < nf; ++j) if (flags2[j] && !flags2[nf + j]) good.push_back(j);
+    if (!good.empty()) {
+        // scatter compact results j -> batch position todo[j] (the scatter kernel walks a (source, destination) list)
+        std::vector<uint32_t> src_dst(2 * good.size());
+        for (size_t i = 0; i < good.size(); ++i) { src_dst[i] = good[i]; src_dst[good.size() + i] = todo[good[i]]; }
+        if ((rc = ix->w2_qidx.ensure(2 * good.size()))) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->w2_qidx.p, src_dst.data(), src_dst.size() * 4, hipMemcpyHostToDevice, s));
+        vdb::launch_scatter_results_list(ix->w2_outi.p, ix->w2_outd.p, ix->w2_outc.p, ix->w2_qidx.p, ix->w2_qidx.p + good.size(),
+                                         (uint32_t)good.size(), (uint32_t)k, d_out_ids, d_out_dists, d_out_counts, s);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return VDB_OK;
+}
+
 // Part 1: checks, workspace, and the FIRST tier enqueued on the stream -- no host synchronisation unless the search is
 // one of the cases answered completely here (empty store, k = 0, k too large for the MFMA tiers).
 int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, const uint64_t* d_idmask,
@@ -676,12 +761,12 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
     if ((rc = ix->w_qp.ensure((size_t)bp_all * ld))) return rc;
     if ((rc = ix->w_qnorm.ensure(bp_all))) return rc;
     if ((rc = ix->w_thr.ensure(bp_all))) return rc;
-    if ((rc = ix->w_flags.ensure(4 + 2 * (size_t)nq32))) return rc;
-    if (ix->h_flags_n < 4 + 2 * (size_t)nq32) {
+    if ((rc = ix->w_flags.ensure(4 + 3 * (size_t)nq32))) return rc;      // status block | cert | overflow | score cut per query
+    if (ix->h_flags_n < 4 + 3 * (size_t)nq32) {
         if (ix->h_flags) (void)hipHostFree(ix->h_flags);
         ix->h_flags = nullptr;
         ix->h_flags_n = 0;
-        size_t want = 4 + 2 * (size_t)nq32 + 1024;
+        size_t want = 4 + 3 * (size_t)nq32 + 1024;
         HIP_TRY(hipHostMalloc((void**)&ix->h_flags, want * 4, hipHostMallocDefault));
         ix->h_flags_n = want;
     }
@@ -691,7 +776,7 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
     // the per-query flags are zeroed by query_prep; the 16-byte status block only needs a memset when the last
     // search left it set (or the buffer is new) -- one launch less at the head of every search
     const bool flags_by_prep = kp != 0 || (ix->screen && plan_bf16(n, k).kp);
-    if (!flags_by_prep) HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, (4 + 2 * (size_t)nq32) * 4, s));
+    if (!flags_by_prep) HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, (4 + 3 * (size_t)nq32) * 4, s));
     else if (ix->status_dirty || ix->w_flags.p != ix->status_buf) {
         HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, 16, s));
         ix->status_buf = ix->w_flags.p;
@@ -745,7 +830,8 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
     if (kp16) {
         ix->stats[8] = 1;
         ix->stats[5] = kp16;
-        if ((rc = pass_bf16(ix, s, nq32, k, pl16, d_rowmask, d_out_ids, d_out_dists, d_out_counts, d_cert, d_ovf, d_status)))
+        if ((rc = pass_bf16(ix, s, nq32, k, pl16, d_rowmask, d_out_ids, d_out_dists, d_out_counts, d_cert, d_ovf, d_status,
+                            reinterpret_cast<float*>(d_ovf + nq32))))
             return rc;
     } else {
         if ((rc = pass_f32(ix, s, ix->w_qp.p, ix->w_qnorm.p, ix->w_thr.p, nq32, k, kp, d_rowmask, d_out_ids, d_out_dists,
@@ -753,7 +839,7 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
             return rc;
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, (4 + 2 * (size_t)nq32) * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, (4 + 3 * (size_t)nq32) * 4, hipMemcpyDeviceToHost, s));
     ix->stats[10] = since();                       // host time until everything of the first tier is enqueued, ns
     Index::SearchCtx& c = ix->ctx;
     c.pending = true; c.nq32 = nq32; c.kp = kp; c.kp16 = kp16; c.k = k; c.s = s; c.d_rowmask = d_rowmask;
@@ -793,6 +879,30 @@ int search_part2(Index* ix, int* changed) {
         todo.push_back(q);
     }
     if (changed && !todo.empty()) *changed = 1;
+    static const bool no_rethr = getenv("VDB_NO_RETHRESHOLD") != nullptr;
+    if (kp16 && !todo.empty() && !no_rethr && !force_exact && !getenv("VDB_FORCE_TIER1")) {
+        // ---- tier 0b: queries with a known score cut get one more HBM-bound pass with that cut as the threshold
+        const uint32_t* h_ovf = ix->h_flags + 4 + nq32;
+        const float* h_cut = reinterpret_cast<const float*>(ix->h_flags + 4 + 2 * (size_t)nq32);
+        std::vector<uint32_t> sel, rest;
+        std::vector<float> cuts;
+        for (uint32_t q : todo) {
+            const float c = h_cut[q];
+            if (!h_ovf[q] && c == c && std::isfinite(c)) { sel.push_back(q); cuts.push_back(c); }
+            else rest.push_back(q);
+        }
+        if (!sel.empty()) {
+            std::vector<uint32_t> fl;
+            if ((rc = pass_rethreshold(ix, s, sel, cuts, k, d_rowmask, d_out_ids, d_out_dists, d_out_counts, d_status, fl))) return rc;
+            const uint32_t nf = (uint32_t)sel.size();
+            for (uint32_t j = 0; j < nf; ++j) {
+                if (fl[j] && !fl[nf + j]) ++ix->stats[13];
+                else { rest.push_back(sel[j]); if (fl[nf + j]) ++ix->stats[2]; }
+            }
+            std::sort(rest.begin(), rest.end());
+        }
+        todo.swap(rest);
+    }
     if (kp16 && !todo.empty()) {
         // ---- second tier: the uncertified queries as one compact block through the f32 MFMA pipeline
         const uint32_t nf = (uint32_t)todo.size(), nfp = round_up(nf, SUPER);
@@ -963,6 +1073,7 @@ void vdb_flat_destroy(vdb_flat_index* ix) {
     ix->w_dense.release(); ix->w_samp.release(); ix->w_pool.release(); ix->w_cand.release(); ix->w_exact.release();
     ix->w_exsel.release(); ix->w_mask_ids.release(); ix->w_outi.release();
     ix->w_qb.release(); ix->w_qerr.release(); ix->w2_qp.release(); ix->w2_qnorm.release(); ix->w2_thr.release(); ix->w2_outd.release();
+    ix->w2_qerr.release(); ix->w2_cand.release(); ix->w2_qb.release();
     ix->w2_outi.release(); ix->w2_outc.release(); ix->w2_flags.release(); ix->w2_qidx.release();
     ix->w_cnt.release(); ix->w_subcnt.release(); ix->w_rowmask.release(); ix->w_flags.release(); ix->w_outc.release();
     if (ix->h_flags) (void)hipHostFree(ix->h_flags);

@@ -255,11 +255,11 @@ class GpuFlatIndex(Index):
         return [out[int(offsets[b]):int(offsets[b + 1])] for b in range(nq)]
 
     def last_stats(self):
-        out = (ctypes.c_uint64 * 13)()
-        self._L.vdb_flat_last_stats_ex(self._h, out, 13)
+        out = (ctypes.c_uint64 * 14)()
+        self._L.vdb_flat_last_stats_ex(self._h, out, 14)
         keys = ["mfma_queries", "exact_queries", "pool_overflows", "rows_scanned", "sample_rows", "kprime",
                 "uncertified", "fused_kernel_ns", "bf16_screen", "f32_tier_queries", "host_enqueued_ns",
-                "host_flags_ns", "host_total_ns"]
+                "host_flags_ns", "host_total_ns", "rethreshold_queries"]
         return dict(zip(keys, [int(v) for v in out]))
 
     def set_screen(self, mode):
