@@ -8,8 +8,11 @@
  * :244-342 insert, :345-381 remove, :386-412 search_knn) operation by operation, including the array layout of
  * Rust's BinaryHeap, which decides the order of equal-distance results (neighbor_queue.rs:102-106).  Every distance the
  * traversal asks for (graph.rs:155, :182, :224) is evaluated on the MI355X, in the reference's exact f32 operation
- * order (distance.rs:37-73), for the candidate lists of ALL in-flight queries of a batch in one launch per traversal
- * round.  There is no CPU distance path.
+ * order (distance.rs:37-73).  Searches run DEVICE-RESIDENT by default (kernels_hnsw.hip): the graph is mirrored in HBM
+ * and one workgroup per query walks it, with the reference's priority queues in LDS -- one launch per batch; what does
+ * not fit that kernel (m > 19, ef > 1022, a walk that overflows its LDS structures, VDB_HNSW_HOST=1) is traversed on
+ * the host with the candidate lists of ALL in-flight queries evaluated in one launch per traversal round.  Both give
+ * the reference's results; there is no CPU distance path.
  *
  * Not reproducible in the reference and fixed here: node levels come from StdRng::from_entropy() (graph.rs:101);
  * this index draws them from a seeded splitmix64 stream (`seed`), with the reference's formula (graph.rs:118-123).
@@ -60,9 +63,11 @@ long vdb_hnsw_neighbors(const vdb_hnsw_index *h, uint64_t id, size_t layer, uint
 long vdb_hnsw_node_level(const vdb_hnsw_index *h, uint64_t id);
 int vdb_hnsw_entry_point(const vdb_hnsw_index *h, uint64_t *id, size_t *max_level);     /* returns 0 when empty */
 
-/* Counters since creation: [0] distances evaluated on the GPU, [1] GPU launches (traversal rounds, row scans and
- * prune batches), [2] traversal rounds of the last search_batch, [3] distances of the last search_batch. */
-int vdb_hnsw_stats(const vdb_hnsw_index *h, uint64_t out[4]);
+/* Counters since creation: [0] distances evaluated on the GPU by the host-driven paths (inserts, host traversal),
+ * [1] GPU launches (device searches, traversal rounds, row scans and prune batches), [2] traversal rounds of the last
+ * HOST-traversed search_batch, [3] its distances, [4] queries answered by the device-resident search, [5] queries whose
+ * device walk overflowed its LDS structures and that the host traversal re-ran. */
+int vdb_hnsw_stats(const vdb_hnsw_index *h, uint64_t out[6]);
 
 #ifdef __cplusplus
 }

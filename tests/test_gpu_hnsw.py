@@ -67,7 +67,37 @@ def test_graph_and_results_equal_the_cpu_restatement(vdb, metric, n, d, m, efc):
     assert_same_results(g, o, queries[:5], 1, 16)
     assert_same_results(g, o, queries[:5], 200, 50)                     # k > ef: ef_actual = k (graph.rs:406)
     st = g.stats()
-    assert st["gpu_distances"] > 0 and st["last_search_rounds"] > 0
+    assert st["gpu_distances"] > 0 and st["device_queries"] == 37 + 5 + 5 and st["host_redone"] == 0, st
+
+
+def test_device_resident_and_host_traversal_agree(vdb):
+    """The same batch through the device-resident search (default) and the host traversal: both are the reference's walk."""
+    import os
+    import subprocess
+    import sys
+    rng = np.random.default_rng(12)
+    rows = rng.random((3000, 40), dtype=np.float32)
+    q = rng.random((64, 40), dtype=np.float32)
+    g, o, ids = build_pair(vdb, 0, rows, 16, 100, 50, seed=2)
+    gi, gd, gc = g.search_batch_arrays(q, 10, 200)
+    assert g.stats()["device_queries"] == 64
+    # m = 24 (lists of up to 49 neighbours) does not fit the device kernel: host traversal, same answers as the oracle
+    g2, o2, _ = build_pair(vdb, 0, rows, 24, 100, 50, seed=2)
+    assert_same_results(g2, o2, q[:9], 10, 64)
+    assert g2.stats()["device_queries"] == 0 and g2.stats()["last_search_rounds"] > 0
+    # VDB_HNSW_HOST=1 is read once per process: a child process runs the same batch on the host path
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from conftest import load_package; vdb = load_package();"
+            "rng = np.random.default_rng(12); rows = rng.random((3000, 40), dtype=np.float32); q = rng.random((64, 40), dtype=np.float32);"
+            "g = vdb.GpuHnswIndex(vdb.DistanceMetric(0), vdb.HnswParams.new(16, 100, 50), seed=2);"
+            "g.build_batch((np.arange(3000, dtype=np.uint64), rows)); i, d, c = g.search_batch_arrays(q, 10, 200);"
+            "assert g.stats()['device_queries'] == 0; np.save(sys.argv[1], i); np.save(sys.argv[2], d.view(np.uint32))") % os.path.dirname(__file__)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        a, b = os.path.join(td, "i.npy"), os.path.join(td, "d.npy")
+        env = dict(os.environ, VDB_HNSW_HOST="1")
+        out = subprocess.run([sys.executable, "-c", code, a, b], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert np.array_equal(np.load(a), gi) and np.array_equal(np.load(b), gd.view(np.uint32))
 
 
 def test_single_adds_equal_bulk_build(vdb):

@@ -285,6 +285,22 @@ void launch_pair_eval(const PairEvalParams& p, hipStream_t s);
 // uncertified / overflowed queries) is non-zero, else 0
 void launch_write_code(const uint32_t* flags, int32_t* code, hipStream_t s);
 
+// ---------------------------------------------------------------- device-resident HNSW search (kernels_hnsw.hip)
+struct HnswSearchParams {
+    const float* rows; uint32_t ld; uint32_t dim; const float* nd; int metric;
+    const float* qp; const float* qnorm;                 // prepared queries
+    // the graph of vdb_hnsw.cpp mirrored in HBM, indexed by node id
+    const uint32_t* row_of; const uint32_t* level; uint32_t n_ids;       // row_of = 0xffffffff: absent / deleted
+    const uint32_t* nbr0; const uint32_t* cnt0; uint32_t stride0;        // layer 0 lists
+    const uint32_t* up_off; const uint32_t* nbrU; const uint32_t* cntU; uint32_t strideU;   // list (id, l >= 1) = up_off[id] + l - 1
+    uint32_t entry_point, max_level, ef, k;
+    uint64_t* out_ids; float* out_dists; uint32_t* out_counts;           // [nq][k]
+    uint32_t* fail;                                                      // [nq]: 1 = structures overflowed, redo on the host
+    uint32_t* status;
+};
+void launch_hnsw_search(const HnswSearchParams& p, uint32_t nq, hipStream_t s);
+bool hnsw_search_supported(uint32_t dim, uint32_t ef, uint32_t k, uint32_t max_list);
+
 void launch_merge_packed(const int32_t* packed, size_t words_per_part, uint32_t nparts, uint32_t nq, uint32_t k,
                          uint64_t* out_ids, float* out_dists, uint32_t* out_counts, uint32_t* out_status, hipStream_t s);
 

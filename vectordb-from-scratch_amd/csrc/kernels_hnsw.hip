@@ -1,0 +1,282 @@
+// kernels_hnsw.hip -- device-resident HNSW search (src/hnsw/graph.rs:143-199 search_layer, :386-412 search_knn):
+// the graph of vdb_hnsw.cpp is mirrored in HBM and ONE workgroup walks it for one query, so a batch needs one launch
+// instead of one launch + host round trip per traversal round.
+//
+// The walk is the reference's, operation by operation.  Thread 0 owns the two priority queues -- Rust's BinaryHeap with
+// the standard library's element moves (neighbor_queue.rs; the backing array decides the order of equal distances in
+// into_sorted_vec) -- in LDS; the neighbour list of the popped candidate is scanned by the lanes of wave 0 (visited set =
+// open-addressing hash in LDS, insertion order restored by a ballot compaction); the distances of the up to 33 unvisited
+// neighbours are evaluated in the reference's exact f32 operation order (distance.rs:37-73): their rows are staged
+// through LDS in chunks of 256 elements by all waves (coalesced), one lane per neighbour folds sequentially and carries
+// its partial sum across chunks.  Anything that does not fit the LDS structures (candidate heap, visited set, ef) sets
+// fail[q]; the host re-runs that query with its own traversal.
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace vdb {
+
+namespace {
+constexpr uint32_t HT = 256;                  // threads per workgroup
+constexpr uint32_t CAND_CAP = 4096;
+constexpr uint32_t RES_CAP = 1024;            // ef + 1 <= RES_CAP
+constexpr uint32_t VIS_CAP = 16384;           // hash slots; at most 3/4 are used
+constexpr uint32_t CH = 256;                  // row elements per staging chunk
+constexpr uint32_t CHS = CH + 4;              // padded LDS stride of a staged row
+constexpr uint32_t MAXP = 40;                 // neighbours per expansion at most (m_max0 + 1 <= 40, i.e. m <= 19)
+
+struct HNb { float d; uint32_t id; };
+
+__device__ __forceinline__ int nb_cmp(const HNb& a, const HNb& b) {      // neighbor_queue.rs:37-43
+    if (a.d < b.d) return -1;
+    if (a.d > b.d) return 1;
+    return a.id < b.id ? -1 : (a.id > b.id ? 1 : 0);
+}
+// Rust BinaryHeap (max-heap under SIGN * nb_cmp) on an LDS array; n is the length.
+template <int SIGN> __device__ __forceinline__ bool h_le(const HNb& a, const HNb& b) { return SIGN * nb_cmp(a, b) <= 0; }
+template <int SIGN> __device__ void h_sift_up(HNb* v, uint32_t start, uint32_t pos) {
+    HNb e = v[pos];
+    while (pos > start) {
+        uint32_t parent = (pos - 1) / 2;
+        HNb pv = v[parent];
+        if (h_le<SIGN>(e, pv)) break;
+        v[pos] = pv;
+        pos = parent;
+    }
+    v[pos] = e;
+}
+template <int SIGN> __device__ void h_push(HNb* v, uint32_t& n, HNb x) { v[n] = x; h_sift_up<SIGN>(v, 0, n); ++n; }
+template <int SIGN> __device__ HNb h_pop(HNb* v, uint32_t& n) {       // n > 0
+    HNb item = v[--n];
+    if (n) {
+        HNb top = v[0];
+        const uint32_t end = n;
+        uint32_t pos = 0, child = 1;
+        HNb e = item;
+        item = top;
+        while (end >= 2 && child <= end - 2) {                          // sift_down_to_bottom
+            HNb c0 = v[child], c1 = v[child + 1];
+            if (h_le<SIGN>(c0, c1)) { ++child; c0 = c1; }
+            v[pos] = c0;
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        if (child == end - 1) { v[pos] = v[child]; pos = child; }
+        v[pos] = e;
+        h_sift_up<SIGN>(v, 0, pos);
+    }
+    return item;
+}
+__device__ __forceinline__ uint32_t vis_hash(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+}  // namespace
+
+__global__ __launch_bounds__(HT) void hnsw_search_kernel(HnswSearchParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t ldq = (p.dim + 3) & ~3u;
+    float* sQ = reinterpret_cast<float*>(smem);                                   // [ldq]
+    HNb* sCand = reinterpret_cast<HNb*>(sQ + ldq);                                // [CAND_CAP]
+    HNb* sRes = sCand + CAND_CAP;                                                 // [RES_CAP]
+    uint32_t* sVis = reinterpret_cast<uint32_t*>(sRes + RES_CAP);                 // [VIS_CAP]
+    float* sStage = reinterpret_cast<float*>(sVis + VIS_CAP);                     // [MAXP][CHS]
+    __shared__ uint32_t sPendId[MAXP], sPendRow[MAXP];
+    __shared__ float sPendD[MAXP];
+    __shared__ uint32_t sNP, sCont, sCur, sFail, sNVis, sZero, sNCand, sNRes;
+    __shared__ uint32_t sKeyD[RES_CAP];      // final stable sort: ordered distance
+    __shared__ uint32_t sKeyI[RES_CAP];      //                    position in the heap's backing array
+
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (uint32_t i = tid; i < ldq; i += HT) sQ[i] = p.qp[(size_t)q * p.ld + i];
+    if (tid == 0) { sFail = 0; sZero = 0; }
+    const float qn = p.qnorm[q];
+    __syncthreads();
+
+    // distances of sPendRow[0..np) into sPendD, in the reference's operation order
+    auto eval_pending = [&](uint32_t np) {
+        float s = 0.0f;
+        const uint32_t d = p.dim;
+        for (uint32_t c0 = 0; c0 < d; c0 += CH) {
+            const uint32_t cl = d - c0 < CH ? d - c0 : CH;          // elements of this chunk
+            const uint32_t nv = (cl + 3) / 4;                       // float4 per row (rows are zero padded up to ld)
+            for (uint32_t r = wv; r < np; r += HT / 64)
+                if (lane < nv)
+                    *reinterpret_cast<float4*>(sStage + r * CHS + 4 * lane) =
+                        *reinterpret_cast<const float4*>(p.rows + (size_t)sPendRow[r] * p.ld + c0 + 4 * lane);
+            __syncthreads();
+            if (tid < np) {
+                const float* x = sStage + tid * CHS;
+                const float* a = sQ + c0;
+                if (p.metric == EUCLID) {
+                    for (uint32_t i = 0; i < cl; ++i) { float t = __fsub_rn(a[i], x[i]); s = __fadd_rn(s, __fmul_rn(t, t)); }
+                } else {
+                    for (uint32_t i = 0; i < cl; ++i) s = __fadd_rn(s, __fmul_rn(a[i], x[i]));
+                }
+            }
+            __syncthreads();
+        }
+        if (tid < np) {
+            float dist;
+            if (p.metric == EUCLID) dist = __builtin_sqrtf(s);
+            else if (p.metric == DOT) dist = -s;
+            else {
+                const float xn = p.nd[sPendRow[tid]];
+                if (qn == 0.0f || xn == 0.0f) { sZero = 1u; dist = 0.0f; }
+                else {
+                    float sim = __fdiv_rn(s, __fmul_rn(qn, xn));
+                    if (sim < -1.0f) sim = -1.0f;
+                    if (sim > 1.0f) sim = 1.0f;
+                    dist = __fsub_rn(1.0f, sim);
+                }
+            }
+            sPendD[tid] = dist;
+        }
+        __syncthreads();
+    };
+
+    uint32_t ep = p.entry_point;
+    const uint32_t ef_final = p.ef > p.k ? p.ef : p.k;
+    for (int layer = (int)p.max_level; layer >= 0; --layer) {
+        const uint32_t ef = layer >= 1 ? 1u : ef_final;
+        // ---- search_layer(query, [ep], ef, layer)   (graph.rs:143-199)
+        for (uint32_t i = tid; i < VIS_CAP; i += HT) sVis[i] = 0xffffffffu;
+        if (tid == 0) {
+            sNCand = 0; sNRes = 0; sNVis = 1;
+            sPendId[0] = ep; sPendRow[0] = p.row_of[ep];
+        }
+        __syncthreads();
+        if (tid == 0) sVis[vis_hash(ep) & (VIS_CAP - 1)] = ep;    // visited.insert(ep), after the clear has completed
+        __syncthreads();
+        eval_pending(1);
+        if (tid == 0) {
+            uint32_t nc = 0, nr = 0;
+            HNb x{sPendD[0], ep};
+            h_push<-1>(sCand, nc, x);
+            h_push<+1>(sRes, nr, x);
+            sNCand = nc; sNRes = nr;
+        }
+        __syncthreads();
+        while (true) {
+            if (tid == 0) {
+                uint32_t nc = sNCand;
+                uint32_t cont = 0;
+                if (nc && !sFail && !sZero) {
+                    HNb c = h_pop<-1>(sCand, nc);
+                    const float furthest = sNRes ? sRes[0].d : 3.40282347e+38f;
+                    if (!(c.d > furthest)) { cont = 1; sCur = c.id; }
+                }
+                sNCand = nc;
+                sCont = cont;
+            }
+            __syncthreads();
+            if (!sCont) break;
+            // ---- neighbours of sCur at this layer: visited filter, in list order
+            const uint32_t cur = sCur;
+            if (wv == 0) {
+                const uint32_t lv = p.level[cur];
+                uint32_t cnt = 0;
+                const uint32_t* lst = nullptr;
+                if ((uint32_t)layer <= lv) {
+                    if (layer == 0) { cnt = p.cnt0[cur]; lst = p.nbr0 + (size_t)cur * p.stride0; }
+                    else { const uint32_t li = p.up_off[cur] + (uint32_t)(layer - 1); cnt = p.cntU[li]; lst = p.nbrU + (size_t)li * p.strideU; }
+                }
+                if (cnt > MAXP) { cnt = MAXP; if (lane == 0) sFail = 1u; }
+                bool keep = false;
+                uint32_t nid = 0xffffffffu, row = 0xffffffffu;
+                if (lane < cnt) {
+                    nid = lst[lane];
+                    // visited.insert(nid): open addressing, CAS claims a slot; an equal key found = already visited
+                    uint32_t h = vis_hash(nid) & (VIS_CAP - 1);
+                    bool fresh = false;
+                    for (uint32_t probe = 0; probe < VIS_CAP; ++probe) {
+                        const uint32_t old = atomicCAS(&sVis[h], 0xffffffffu, nid);
+                        if (old == 0xffffffffu) { fresh = true; break; }
+                        if (old == nid) break;
+                        h = (h + 1) & (VIS_CAP - 1);
+                    }
+                    if (fresh) {
+                        atomicAdd(&sNVis, 1u);
+                        row = nid < p.n_ids ? p.row_of[nid] : 0xffffffffu;
+                        keep = row != 0xffffffffu;                       // skip deleted nodes
+                    }
+                }
+                const unsigned long long m = __ballot(keep);
+                const uint32_t pos = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (keep) { sPendId[pos] = nid; sPendRow[pos] = row; }
+                if (lane == 0) {
+                    sNP = (uint32_t)__popcll(m);
+                    if (sNVis > (VIS_CAP / 4) * 3) sFail = 1u;
+                }
+            }
+            __syncthreads();
+            const uint32_t np = sNP;
+            if (np == 0) continue;
+            eval_pending(np);
+            if (tid == 0) {
+                uint32_t nc = sNCand, nr = sNRes;
+                for (uint32_t i = 0; i < np; ++i) {
+                    const float dd = sPendD[i];
+                    const float furthest = nr ? sRes[0].d : 3.40282347e+38f;
+                    if (dd < furthest || nr < ef) {
+                        if (nc >= CAND_CAP || nr >= RES_CAP) { sFail = 1u; break; }
+                        HNb x{dd, sPendId[i]};
+                        h_push<-1>(sCand, nc, x);
+                        h_push<+1>(sRes, nr, x);
+                        if (nr > ef) (void)h_pop<+1>(sRes, nr);
+                    }
+                }
+                sNCand = nc; sNRes = nr;
+            }
+            __syncthreads();
+        }
+        if (sFail || sZero) break;
+        // ---- results.into_sorted_vec(): stable sort of the heap's backing array by distance (bitonic on (distance, position))
+        const uint32_t nr = sNRes;
+        uint32_t P = 2;
+        while (P < nr) P <<= 1;
+        for (uint32_t i = tid; i < P; i += HT) {
+            sKeyD[i] = i < nr ? f32_to_ordered(sRes[i].d) : 0xffffffffu;
+            sKeyI[i] = i;
+        }
+        __syncthreads();
+        for (uint32_t size = 2; size <= P; size <<= 1)
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (uint32_t t = tid; t < P / 2; t += HT) {
+                    uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                    bool up = ((lo & size) == 0);
+                    uint32_t da = sKeyD[lo], db = sKeyD[hi], ia = sKeyI[lo], ib = sKeyI[hi];
+                    bool gt = da > db || (da == db && ia > ib);
+                    if (gt == up) { sKeyD[lo] = db; sKeyD[hi] = da; sKeyI[lo] = ib; sKeyI[hi] = ia; }
+                }
+                __syncthreads();
+            }
+        if (layer >= 1) {
+            if (nr) ep = sRes[sKeyI[0]].id;                                  // nearest.first()
+            __syncthreads();
+        } else {
+            const uint32_t cnt = nr < p.k ? nr : p.k;
+            for (uint32_t i = tid; i < cnt; i += HT) {
+                const HNb x = sRes[sKeyI[i]];
+                p.out_ids[(size_t)q * p.k + i] = (uint64_t)x.id;
+                p.out_dists[(size_t)q * p.k + i] = x.d;
+            }
+            if (tid == 0) p.out_counts[q] = cnt;
+        }
+    }
+    if (tid == 0) {
+        p.fail[q] = sFail ? 1u : 0u;
+        if (sZero) atomicOr(p.status, ST_ZERO_QUERY);
+    }
+}
+
+size_t hnsw_search_lds_bytes(uint32_t dim) {
+    const uint32_t ldq = (dim + 3) & ~3u;
+    return (size_t)ldq * 4 + (size_t)CAND_CAP * 8 + (size_t)RES_CAP * 8 + (size_t)VIS_CAP * 4 + (size_t)MAXP * CHS * 4;
+}
+bool hnsw_search_supported(uint32_t dim, uint32_t ef, uint32_t k, uint32_t max_list) {
+    return (ef > k ? ef : k) + 1 <= RES_CAP && max_list <= MAXP && hnsw_search_lds_bytes(dim) <= 150 * 1024;   // + ~9 KB static
+}
+void launch_hnsw_search(const HnswSearchParams& p, uint32_t nq, hipStream_t s) {
+    if (!nq) return;
+    hipLaunchKernelGGL(hnsw_search_kernel, dim3(nq), dim3(HT), hnsw_search_lds_bytes(p.dim), s, p);
+}
+
+}  // namespace vdb

@@ -1574,6 +1574,15 @@ uint32_t row_of(vdb_flat_index* ix, uint64_t id) {
     return it == ix->id2row.end() ? 0xffffffffu : it->second;
 }
 uint32_t n_rows(vdb_flat_index* ix) { return ix->n_rows(); }
+int device_view(vdb_flat_index* ix, DeviceView* out) {
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc;
+    if ((rc = set_device(ix))) return rc;
+    if ((rc = ix->w_flags.ensure(4))) return rc;
+    out->rows = ix->d_rows; out->ld = ix->ld; out->dim = ix->dim; out->nd = ix->d_nd; out->qp = ix->w_qp.p; out->qnorm = ix->w_qnorm.p;
+    out->metric = ix->metric; out->stream = (void*)ix->stream; out->status = ix->w_flags.p;
+    return VDB_OK;
+}
 int set_error(int code, const char* msg) { return fail(code, "%s", msg); }
 int set_dim_error(size_t expected, size_t actual) { return fail_dim(expected, actual); }
 

@@ -23,6 +23,7 @@
 #include "../../include/vdb_flat.h"
 #include "../../include/vdb_hnsw.h"
 #include "vdb_internal.h"
+#include "kernels.h"
 
 namespace {
 
@@ -121,6 +122,13 @@ struct vdb_hnsw_index {
     size_t count = 0, dim = 0;
     std::mutex mu;
     uint64_t stats[4] = {0, 0, 0, 0};
+    // the graph mirrored in HBM for the device-resident search (kernels_hnsw.hip); rebuilt when the graph changed
+    uint64_t graph_version = 1, mirror_version = 0;
+    uint32_t *d_row_of = nullptr, *d_level = nullptr, *d_nbr0 = nullptr, *d_cnt0 = nullptr, *d_up_off = nullptr, *d_nbrU = nullptr, *d_cntU = nullptr;
+    uint64_t* d_out_ids = nullptr; float* d_out_dists = nullptr; uint32_t *d_out_counts = nullptr, *d_fail = nullptr;
+    size_t out_cap = 0, out_nq_cap = 0;
+    uint32_t mirror_ids = 0, stride0 = 0, strideU = 0, max_list = 0;
+    uint64_t device_queries = 0, host_redone = 0;
     const Node* node(uint64_t id) const { return id < nodes.size() && nodes[id].present ? &nodes[id] : nullptr; }
 };
 
@@ -213,6 +221,7 @@ double next_unit(Graph* g) {
 int insert_node(Graph* g, uint64_t id, uint32_t row, long level_in, const float* scan) {
     const size_t level = level_in >= 0 ? std::min<size_t>((size_t)level_in, g->max_layers - 1) : level_from_unit(g, next_unit(g));
     if (id >= g->nodes.size()) g->nodes.resize(id + 1);
+    g->graph_version++;
     Node& nd = g->nodes[id];
     nd = Node();
     nd.present = true; nd.level = (uint32_t)level; nd.row = row;
@@ -316,6 +325,8 @@ int add_rows(Graph* g, const uint64_t* ids, uint64_t first_id, const float* rows
     return VDB_OK;
 }
 
+void free_mirror(vdb_hnsw_index* g);
+
 }  // namespace
 
 extern "C" {
@@ -337,6 +348,7 @@ int vdb_hnsw_create(int metric, size_t m, size_t ef_construction, size_t ef_sear
 
 void vdb_hnsw_destroy(vdb_hnsw_index* g) {
     if (!g) return;
+    free_mirror(g);
     vdb_flat_destroy(g->flat);
     delete g;
 }
@@ -357,6 +369,7 @@ int vdb_hnsw_remove(vdb_hnsw_index* g, uint64_t id) {             // graph.rs:34
     if (!g) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null handle");
     std::lock_guard<std::mutex> lk(g->mu);
     if (!g->node(id)) return VDB_OK;
+    g->graph_version++;
     Node gone = std::move(g->nodes[id]);
     g->nodes[id] = Node();
     for (size_t l = 0; l < gone.nbr.size(); ++l)
@@ -377,15 +390,14 @@ int vdb_hnsw_remove(vdb_hnsw_index* g, uint64_t id) {             // graph.rs:34
     return rc;
 }
 
-int vdb_hnsw_search_batch(vdb_hnsw_index* g, const float* queries, size_t nq, size_t dim, size_t k, size_t ef,
-                          uint64_t* out_ids, float* out_dists, size_t* out_counts) {
-    if (!g || (nq && (!queries || !out_counts || (k && (!out_ids || !out_dists)))))
-        return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null argument");
-    std::lock_guard<std::mutex> lk(g->mu);
-    for (size_t b = 0; b < nq; ++b) out_counts[b] = 0;
-    g->stats[2] = g->stats[3] = 0;
-    if (nq == 0 || !g->has_ep) return VDB_OK;                     // graph.rs:392-395: empty graph -> Ok(vec![])
-    if (dim != g->dim) return vdb_internal::set_dim_error(dim, g->dim);   // distance.rs:21-26 on the first evaluation
+}  // extern "C"
+
+namespace {
+
+// host traversal (one GPU launch per round for the candidate lists of every query): the path for what the device-resident
+// search does not take (m > 19, ef > 1022, overflowing queries, VDB_HNSW_HOST=1)
+int search_host(vdb_hnsw_index* g, const float* queries, size_t nq, size_t dim, size_t k, size_t ef,
+                uint64_t* out_ids, float* out_dists, size_t* out_counts) {
     int rc;
     if ((rc = vdb_internal::pairs_begin(g->flat, queries, nq, dim))) return rc;
     const size_t ef_actual = std::max(ef ? ef : g->ef_search, k);
@@ -490,6 +502,155 @@ int vdb_hnsw_search_batch(vdb_hnsw_index* g, const float* queries, size_t nq, si
     return VDB_OK;
 }
 
+#define HN_TRY(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return vdb_internal::set_error(VDB_ERR_DEVICE, hipGetErrorString(e_));       \
+    } while (0)
+
+void free_mirror(vdb_hnsw_index* g) {
+    for (uint32_t** p : {&g->d_row_of, &g->d_level, &g->d_nbr0, &g->d_cnt0, &g->d_up_off, &g->d_nbrU, &g->d_cntU, &g->d_out_counts, &g->d_fail})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (g->d_out_ids) { (void)hipFree(g->d_out_ids); g->d_out_ids = nullptr; }
+    if (g->d_out_dists) { (void)hipFree(g->d_out_dists); g->d_out_dists = nullptr; }
+    g->out_cap = g->out_nq_cap = 0;
+    g->mirror_version = 0;
+}
+
+// Mirrors the graph into HBM (kernels.h HnswSearchParams): per node id its device row (0xffffffff = absent), level,
+// layer-0 list, and the offset of its upper-layer lists in a pooled array.
+int upload_mirror(vdb_hnsw_index* g, hipStream_t s) {
+    if (g->mirror_version == g->graph_version) return VDB_OK;
+    const uint32_t n = (uint32_t)g->nodes.size();
+    uint32_t max0 = 1, maxU = 1, n_upper = 0;
+    for (const Node& nd : g->nodes) {
+        if (!nd.present) continue;
+        max0 = std::max<uint32_t>(max0, (uint32_t)nd.nbr[0].size());
+        for (size_t l = 1; l < nd.nbr.size(); ++l) maxU = std::max<uint32_t>(maxU, (uint32_t)nd.nbr[l].size());
+        n_upper += nd.level;
+    }
+    std::vector<uint32_t> row_of(n, 0xffffffffu), level(n, 0), cnt0(n, 0), up_off(n, 0), nbr0((size_t)n * max0, 0xffffffffu);
+    std::vector<uint32_t> nbrU((size_t)std::max<uint32_t>(n_upper, 1) * maxU, 0xffffffffu), cntU(std::max<uint32_t>(n_upper, 1), 0);
+    uint32_t off = 0;
+    for (uint32_t id = 0; id < n; ++id) {
+        const Node& nd = g->nodes[id];
+        if (!nd.present) continue;
+        row_of[id] = nd.row; level[id] = nd.level; cnt0[id] = (uint32_t)nd.nbr[0].size(); up_off[id] = off;
+        for (size_t i = 0; i < nd.nbr[0].size(); ++i) nbr0[(size_t)id * max0 + i] = (uint32_t)nd.nbr[0][i];
+        for (size_t l = 1; l < nd.nbr.size(); ++l) {
+            cntU[off + l - 1] = (uint32_t)nd.nbr[l].size();
+            for (size_t i = 0; i < nd.nbr[l].size(); ++i) nbrU[(size_t)(off + l - 1) * maxU + i] = (uint32_t)nd.nbr[l][i];
+        }
+        off += nd.level;
+    }
+    for (uint32_t** p : {&g->d_row_of, &g->d_level, &g->d_nbr0, &g->d_cnt0, &g->d_up_off, &g->d_nbrU, &g->d_cntU})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    auto up = [&](uint32_t** dst, const std::vector<uint32_t>& v) -> int {
+        HN_TRY(hipMalloc((void**)dst, std::max<size_t>(v.size(), 1) * 4));
+        if (!v.empty()) HN_TRY(hipMemcpyAsync(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice, s));
+        return VDB_OK;
+    };
+    int rc;
+    if ((rc = up(&g->d_row_of, row_of)) || (rc = up(&g->d_level, level)) || (rc = up(&g->d_nbr0, nbr0)) || (rc = up(&g->d_cnt0, cnt0)) ||
+        (rc = up(&g->d_up_off, up_off)) || (rc = up(&g->d_nbrU, nbrU)) || (rc = up(&g->d_cntU, cntU)))
+        return rc;
+    HN_TRY(hipStreamSynchronize(s));                                   // the staging vectors go out of scope
+    g->mirror_ids = n; g->stride0 = max0; g->strideU = maxU; g->max_list = std::max(max0, maxU);
+    g->mirror_version = g->graph_version;
+    return VDB_OK;
+}
+
+// device-resident search of the whole batch in one launch; queries whose walk overflowed the kernel's LDS structures are
+// listed in `redo`
+int search_device(vdb_hnsw_index* g, const float* queries, size_t nq, size_t dim, size_t k, size_t ef_actual,
+                  uint64_t* out_ids, float* out_dists, size_t* out_counts, std::vector<uint32_t>& redo) {
+    int rc;
+    if ((rc = vdb_internal::pairs_begin(g->flat, queries, nq, dim))) return rc;
+    vdb_internal::DeviceView dv;
+    if ((rc = vdb_internal::device_view(g->flat, &dv))) return rc;
+    hipStream_t s = (hipStream_t)dv.stream;
+    if ((rc = upload_mirror(g, s))) return rc;
+    const size_t need = nq * std::max<size_t>(k, 1);
+    if (need > g->out_cap || nq > g->out_nq_cap) {
+        if (g->d_out_ids) (void)hipFree(g->d_out_ids);
+        if (g->d_out_dists) (void)hipFree(g->d_out_dists);
+        if (g->d_out_counts) (void)hipFree(g->d_out_counts);
+        if (g->d_fail) (void)hipFree(g->d_fail);
+        g->d_out_ids = nullptr; g->d_out_dists = nullptr; g->d_out_counts = g->d_fail = nullptr; g->out_cap = g->out_nq_cap = 0;
+        HN_TRY(hipMalloc((void**)&g->d_out_ids, need * 8));
+        HN_TRY(hipMalloc((void**)&g->d_out_dists, need * 4));
+        HN_TRY(hipMalloc((void**)&g->d_out_counts, nq * 4));
+        HN_TRY(hipMalloc((void**)&g->d_fail, nq * 4));
+        g->out_cap = need; g->out_nq_cap = nq;
+    }
+    HN_TRY(hipMemsetAsync(dv.status, 0, 16, s));
+    vdb::HnswSearchParams hp{};
+    hp.rows = dv.rows; hp.ld = dv.ld; hp.dim = dv.dim; hp.nd = dv.nd; hp.metric = dv.metric; hp.qp = dv.qp; hp.qnorm = dv.qnorm;
+    hp.row_of = g->d_row_of; hp.level = g->d_level; hp.n_ids = g->mirror_ids; hp.nbr0 = g->d_nbr0; hp.cnt0 = g->d_cnt0; hp.stride0 = g->stride0;
+    hp.up_off = g->d_up_off; hp.nbrU = g->d_nbrU; hp.cntU = g->d_cntU; hp.strideU = g->strideU;
+    hp.entry_point = (uint32_t)g->ep; hp.max_level = (uint32_t)g->max_level; hp.ef = (uint32_t)ef_actual; hp.k = (uint32_t)k;
+    hp.out_ids = g->d_out_ids; hp.out_dists = g->d_out_dists; hp.out_counts = g->d_out_counts; hp.fail = g->d_fail; hp.status = dv.status;
+    vdb::launch_hnsw_search(hp, (uint32_t)nq, s);
+    HN_TRY(hipGetLastError());
+    std::vector<uint32_t> cnt(nq), fail(nq);
+    uint32_t status = 0;
+    HN_TRY(hipMemcpyAsync(cnt.data(), g->d_out_counts, nq * 4, hipMemcpyDeviceToHost, s));
+    HN_TRY(hipMemcpyAsync(fail.data(), g->d_fail, nq * 4, hipMemcpyDeviceToHost, s));
+    HN_TRY(hipMemcpyAsync(&status, dv.status, 4, hipMemcpyDeviceToHost, s));
+    if (k) {
+        HN_TRY(hipMemcpyAsync(out_ids, g->d_out_ids, nq * k * 8, hipMemcpyDeviceToHost, s));
+        HN_TRY(hipMemcpyAsync(out_dists, g->d_out_dists, nq * k * 4, hipMemcpyDeviceToHost, s));
+    }
+    HN_TRY(hipStreamSynchronize(s));
+    g->stats[1]++;
+    if (status & 2u) return zero_norm_error();                     // ST_ZERO_QUERY
+    for (size_t b = 0; b < nq; ++b) {
+        if (fail[b]) { redo.push_back((uint32_t)b); out_counts[b] = 0; }
+        else out_counts[b] = cnt[b];
+    }
+    g->device_queries += nq - redo.size();
+    return VDB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vdb_hnsw_search_batch(vdb_hnsw_index* g, const float* queries, size_t nq, size_t dim, size_t k, size_t ef,
+                          uint64_t* out_ids, float* out_dists, size_t* out_counts) {
+    if (!g || (nq && (!queries || !out_counts || (k && (!out_ids || !out_dists)))))
+        return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    for (size_t b = 0; b < nq; ++b) out_counts[b] = 0;
+    g->stats[2] = g->stats[3] = 0;
+    if (nq == 0 || !g->has_ep) return VDB_OK;                     // graph.rs:392-395: empty graph -> Ok(vec![])
+    if (dim != g->dim) return vdb_internal::set_dim_error(dim, g->dim);   // distance.rs:21-26 on the first evaluation
+    const size_t ef_actual = std::max(ef ? ef : g->ef_search, k);
+    static const bool host_only = getenv("VDB_HNSW_HOST") != nullptr;
+    const bool on_device = !host_only && k > 0 && g->nodes.size() < 0xffffffffull &&
+                           vdb::hnsw_search_supported((uint32_t)g->dim, (uint32_t)std::min<size_t>(ef_actual, 0xffffffu), (uint32_t)std::min<size_t>(k, 0xffffffu),
+                                                      (uint32_t)std::max(g->m_max0, g->m) + 1);
+    if (!on_device) return search_host(g, queries, nq, dim, k, ef, out_ids, out_dists, out_counts);
+    int rc;
+    std::vector<uint32_t> redo;
+    if ((rc = search_device(g, queries, nq, dim, k, ef_actual, out_ids, out_dists, out_counts, redo))) return rc;
+    if (!redo.empty()) {                                            // the walks that did not fit the kernel's LDS structures
+        g->host_redone += redo.size();
+        std::vector<float> q2(redo.size() * dim);
+        for (size_t j = 0; j < redo.size(); ++j) memcpy(q2.data() + j * dim, queries + (size_t)redo[j] * dim, dim * sizeof(float));
+        std::vector<uint64_t> i2(redo.size() * k);
+        std::vector<float> d2(redo.size() * k);
+        std::vector<size_t> c2(redo.size());
+        if ((rc = search_host(g, q2.data(), redo.size(), dim, k, ef, i2.data(), d2.data(), c2.data()))) return rc;
+        for (size_t j = 0; j < redo.size(); ++j) {
+            memcpy(out_ids + (size_t)redo[j] * k, i2.data() + j * k, k * 8);
+            memcpy(out_dists + (size_t)redo[j] * k, d2.data() + j * k, k * 4);
+            out_counts[redo[j]] = c2[j];
+        }
+    }
+    return VDB_OK;
+}
+
 size_t vdb_hnsw_len(const vdb_hnsw_index* g) { return g ? g->count : 0; }
 int vdb_hnsw_metric(const vdb_hnsw_index* g) { return g ? g->metric : -1; }
 
@@ -517,9 +678,11 @@ int vdb_hnsw_entry_point(const vdb_hnsw_index* g, uint64_t* id, size_t* max_leve
     if (max_level) *max_level = g->max_level;
     return g->has_ep ? 1 : 0;
 }
-int vdb_hnsw_stats(const vdb_hnsw_index* g, uint64_t out[4]) {
+int vdb_hnsw_stats(const vdb_hnsw_index* g, uint64_t out[6]) {
     if (!g || !out) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null argument");
     memcpy(out, g->stats, sizeof(g->stats));
+    out[4] = g->device_queries;
+    out[5] = g->host_redone;
     return VDB_OK;
 }
 

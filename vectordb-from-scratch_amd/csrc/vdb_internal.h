@@ -24,6 +24,9 @@ int query_vs_rows(vdb_flat_index* ix, uint32_t q, uint32_t n_rows, float* out);
 // device row of a stored id (0xffffffff: absent, or a row of another dimension kept host-side)
 uint32_t row_of(vdb_flat_index* ix, uint64_t id);
 uint32_t n_rows(vdb_flat_index* ix);
+// device pointers of the row store and of the query block prepared by pairs_begin (valid until the next call on the handle)
+struct DeviceView { const float* rows; uint32_t ld, dim; const float* nd; const float* qp; const float* qnorm; int metric; void* stream; uint32_t* status; };
+int device_view(vdb_flat_index* ix, DeviceView* out);
 // thread-local last-error state shared by every entry point of the library (vdb_last_error)
 int set_error(int code, const char* msg);
 int set_dim_error(size_t expected, size_t actual);

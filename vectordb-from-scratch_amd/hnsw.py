@@ -141,6 +141,7 @@ class GpuHnswIndex(Index):
         return (int(ep.value), int(ml.value)) if has else (None, 0)
 
     def stats(self):
-        out = (ctypes.c_uint64 * 4)()
+        out = (ctypes.c_uint64 * 6)()
         self._L.vdb_hnsw_stats(self._h, out)
-        return dict(zip(["gpu_distances", "gpu_launches", "last_search_rounds", "last_search_distances"], [int(v) for v in out]))
+        return dict(zip(["gpu_distances", "gpu_launches", "last_search_rounds", "last_search_distances", "device_queries",
+                         "host_redone"], [int(v) for v in out]))
