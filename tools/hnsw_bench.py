@@ -61,7 +61,7 @@ def main():
     t_f = (time.perf_counter() - t0) / reps
     rec = np.mean([len(set(ti[b]) & set(hi[b, :hc[b]])) / float(a.k) for b in range(a.batch)])
     print(f"search: batch {a.batch}, k={a.k}, ef={a.ef}: {1e3 * t_s:.2f} ms per batch = {a.batch / t_s:.0f} queries/s; "
-          f"{st['last_search_rounds']} traversal rounds (one launch each), {st['last_search_distances'] / a.batch:.0f} distances per query; "
+          f"device-resident walks {st['device_queries']}, host re-runs {st['host_redone']}, host traversal rounds of the last batch {st['last_search_rounds']}; "
           f"recall@{a.k} vs exact = {rec:.4f}; exact GPU FlatIndex on the same batch (host pointers): {a.batch / t_f:.0f} queries/s", flush=True)
     if a.oracle:
         import oracle

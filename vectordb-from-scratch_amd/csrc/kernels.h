@@ -290,9 +290,11 @@ struct HnswSearchParams {
     const float* rows; uint32_t ld; uint32_t dim; const float* nd; int metric;
     const float* qp; const float* qnorm;                 // prepared queries
     // the graph of vdb_hnsw.cpp mirrored in HBM, indexed by node id
-    const uint32_t* row_of; const uint32_t* level; uint32_t n_ids;       // row_of = 0xffffffff: absent / deleted
-    const uint32_t* nbr0; const uint32_t* cnt0; uint32_t stride0;        // layer 0 lists
-    const uint32_t* up_off; const uint32_t* nbrU; const uint32_t* cntU; uint32_t strideU;   // list (id, l >= 1) = up_off[id] + l - 1
+    const uint32_t* row_of; uint32_t n_ids;                              // row_of = 0xffffffff: absent / deleted
+    // lists are padded with 0xffffffff; *_row holds the device row of each listed neighbour (0xffffffff = deleted)
+    const uint32_t* nbr0; const uint32_t* nbr0_row; uint32_t stride0;    // layer 0 lists
+    const uint32_t* up_off; const uint32_t* nbrU; const uint32_t* nbrU_row; uint32_t strideU;   // list (id, l >= 1) = up_off[id] + l - 1
+    const uint32_t* level; const uint32_t* cnt0; const uint32_t* cntU;   // (unused by the kernel; kept for inspection)
     uint32_t entry_point, max_level, ef, k;
     uint64_t* out_ids; float* out_dists; uint32_t* out_counts;           // [nq][k]
     uint32_t* fail;                                                      // [nq]: 1 = structures overflowed, redo on the host

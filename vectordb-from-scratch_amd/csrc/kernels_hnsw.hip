@@ -26,6 +26,8 @@ constexpr uint32_t CHS = CH + 4;              // padded LDS stride of a staged r
 constexpr uint32_t MAXP = 40;                 // neighbours per expansion at most (m_max0 + 1 <= 40, i.e. m <= 19)
 
 struct HNb { float d; uint32_t id; };
+typedef __attribute__((address_space(3))) void* hn_lds_t;
+typedef const __attribute__((address_space(1))) void* hn_glb_t;
 
 __device__ __forceinline__ int nb_cmp(const HNb& a, const HNb& b) {      // neighbor_queue.rs:37-43
     if (a.d < b.d) return -1;
@@ -97,18 +99,37 @@ __global__ __launch_bounds__(HT) void hnsw_search_kernel(HnswSearchParams p) {
         for (uint32_t c0 = 0; c0 < d; c0 += CH) {
             const uint32_t cl = d - c0 < CH ? d - c0 : CH;          // elements of this chunk
             const uint32_t nv = (cl + 3) / 4;                       // float4 per row (rows are zero padded up to ld)
+            // one LDS-DMA instruction moves a row's whole chunk (64 lanes x 16 B = 256 elements); every row of the
+            // expansion is in flight at once, the barrier's vmcnt(0) waits for them
             for (uint32_t r = wv; r < np; r += HT / 64)
                 if (lane < nv)
-                    *reinterpret_cast<float4*>(sStage + r * CHS + 4 * lane) =
-                        *reinterpret_cast<const float4*>(p.rows + (size_t)sPendRow[r] * p.ld + c0 + 4 * lane);
+                    __builtin_amdgcn_global_load_lds((hn_glb_t)(p.rows + (size_t)sPendRow[r] * p.ld + c0 + 4 * lane),
+                                                     (hn_lds_t)(sStage + r * CHS), 16, 0, 0);
             __syncthreads();
             if (tid < np) {
                 const float* x = sStage + tid * CHS;
                 const float* a = sQ + c0;
+                // 16-byte LDS reads, the adds stay one strictly sequential chain (the reference's fold order)
+                const uint32_t c4 = cl & ~3u;
                 if (p.metric == EUCLID) {
-                    for (uint32_t i = 0; i < cl; ++i) { float t = __fsub_rn(a[i], x[i]); s = __fadd_rn(s, __fmul_rn(t, t)); }
+                    for (uint32_t i = 0; i < c4; i += 4) {
+                        const float4 av = *reinterpret_cast<const float4*>(a + i), xv = *reinterpret_cast<const float4*>(x + i);
+                        float t;
+                        t = __fsub_rn(av.x, xv.x); s = __fadd_rn(s, __fmul_rn(t, t));
+                        t = __fsub_rn(av.y, xv.y); s = __fadd_rn(s, __fmul_rn(t, t));
+                        t = __fsub_rn(av.z, xv.z); s = __fadd_rn(s, __fmul_rn(t, t));
+                        t = __fsub_rn(av.w, xv.w); s = __fadd_rn(s, __fmul_rn(t, t));
+                    }
+                    for (uint32_t i = c4; i < cl; ++i) { float t = __fsub_rn(a[i], x[i]); s = __fadd_rn(s, __fmul_rn(t, t)); }
                 } else {
-                    for (uint32_t i = 0; i < cl; ++i) s = __fadd_rn(s, __fmul_rn(a[i], x[i]));
+                    for (uint32_t i = 0; i < c4; i += 4) {
+                        const float4 av = *reinterpret_cast<const float4*>(a + i), xv = *reinterpret_cast<const float4*>(x + i);
+                        s = __fadd_rn(s, __fmul_rn(av.x, xv.x));
+                        s = __fadd_rn(s, __fmul_rn(av.y, xv.y));
+                        s = __fadd_rn(s, __fmul_rn(av.z, xv.z));
+                        s = __fadd_rn(s, __fmul_rn(av.w, xv.w));
+                    }
+                    for (uint32_t i = c4; i < cl; ++i) s = __fadd_rn(s, __fmul_rn(a[i], x[i]));
                 }
             }
             __syncthreads();
@@ -171,18 +192,19 @@ __global__ __launch_bounds__(HT) void hnsw_search_kernel(HnswSearchParams p) {
             // ---- neighbours of sCur at this layer: visited filter, in list order
             const uint32_t cur = sCur;
             if (wv == 0) {
-                const uint32_t lv = p.level[cur];
-                uint32_t cnt = 0;
-                const uint32_t* lst = nullptr;
-                if ((uint32_t)layer <= lv) {
-                    if (layer == 0) { cnt = p.cnt0[cur]; lst = p.nbr0 + (size_t)cur * p.stride0; }
-                    else { const uint32_t li = p.up_off[cur] + (uint32_t)(layer - 1); cnt = p.cntU[li]; lst = p.nbrU + (size_t)li * p.strideU; }
+                // the whole list in ONE load per lane: lists are padded with 0xffffffff and carry the device row of each
+                // neighbour (0xffffffff = deleted) beside its id, so no count / level / row lookup precedes the distances
+                const uint32_t* lst; const uint32_t* lrow; uint32_t stride;
+                if (layer == 0) { lst = p.nbr0 + (size_t)cur * p.stride0; lrow = p.nbr0_row + (size_t)cur * p.stride0; stride = p.stride0; }
+                else {
+                    const uint32_t li = p.up_off[cur] + (uint32_t)(layer - 1);
+                    lst = p.nbrU + (size_t)li * p.strideU; lrow = p.nbrU_row + (size_t)li * p.strideU; stride = p.strideU;
                 }
-                if (cnt > MAXP) { cnt = MAXP; if (lane == 0) sFail = 1u; }
+                if (stride > MAXP) { stride = MAXP; if (lane == 0) sFail = 1u; }
                 bool keep = false;
                 uint32_t nid = 0xffffffffu, row = 0xffffffffu;
-                if (lane < cnt) {
-                    nid = lst[lane];
+                if (lane < stride) { nid = lst[lane]; row = lrow[lane]; }
+                if (nid != 0xffffffffu) {
                     // visited.insert(nid): open addressing, CAS claims a slot; an equal key found = already visited
                     uint32_t h = vis_hash(nid) & (VIS_CAP - 1);
                     bool fresh = false;
@@ -194,7 +216,6 @@ __global__ __launch_bounds__(HT) void hnsw_search_kernel(HnswSearchParams p) {
                     }
                     if (fresh) {
                         atomicAdd(&sNVis, 1u);
-                        row = nid < p.n_ids ? p.row_of[nid] : 0xffffffffu;
                         keep = row != 0xffffffffu;                       // skip deleted nodes
                     }
                 }

@@ -125,6 +125,7 @@ struct vdb_hnsw_index {
     // the graph mirrored in HBM for the device-resident search (kernels_hnsw.hip); rebuilt when the graph changed
     uint64_t graph_version = 1, mirror_version = 0;
     uint32_t *d_row_of = nullptr, *d_level = nullptr, *d_nbr0 = nullptr, *d_cnt0 = nullptr, *d_up_off = nullptr, *d_nbrU = nullptr, *d_cntU = nullptr;
+    uint32_t *d_nbr0_row = nullptr, *d_nbrU_row = nullptr;
     uint64_t* d_out_ids = nullptr; float* d_out_dists = nullptr; uint32_t *d_out_counts = nullptr, *d_fail = nullptr;
     size_t out_cap = 0, out_nq_cap = 0;
     uint32_t mirror_ids = 0, stride0 = 0, strideU = 0, max_list = 0;
@@ -509,7 +510,7 @@ int search_host(vdb_hnsw_index* g, const float* queries, size_t nq, size_t dim, 
     } while (0)
 
 void free_mirror(vdb_hnsw_index* g) {
-    for (uint32_t** p : {&g->d_row_of, &g->d_level, &g->d_nbr0, &g->d_cnt0, &g->d_up_off, &g->d_nbrU, &g->d_cntU, &g->d_out_counts, &g->d_fail})
+    for (uint32_t** p : {&g->d_row_of, &g->d_level, &g->d_nbr0, &g->d_cnt0, &g->d_up_off, &g->d_nbrU, &g->d_cntU, &g->d_nbr0_row, &g->d_nbrU_row, &g->d_out_counts, &g->d_fail})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     if (g->d_out_ids) { (void)hipFree(g->d_out_ids); g->d_out_ids = nullptr; }
     if (g->d_out_dists) { (void)hipFree(g->d_out_dists); g->d_out_dists = nullptr; }
@@ -531,19 +532,21 @@ int upload_mirror(vdb_hnsw_index* g, hipStream_t s) {
     }
     std::vector<uint32_t> row_of(n, 0xffffffffu), level(n, 0), cnt0(n, 0), up_off(n, 0), nbr0((size_t)n * max0, 0xffffffffu);
     std::vector<uint32_t> nbrU((size_t)std::max<uint32_t>(n_upper, 1) * maxU, 0xffffffffu), cntU(std::max<uint32_t>(n_upper, 1), 0);
+    std::vector<uint32_t> nbr0_row(nbr0.size(), 0xffffffffu), nbrU_row(nbrU.size(), 0xffffffffu);
+    auto row_now = [&](uint64_t x) -> uint32_t { const Node* t = g->node(x); return t ? t->row : 0xffffffffu; };
     uint32_t off = 0;
     for (uint32_t id = 0; id < n; ++id) {
         const Node& nd = g->nodes[id];
         if (!nd.present) continue;
         row_of[id] = nd.row; level[id] = nd.level; cnt0[id] = (uint32_t)nd.nbr[0].size(); up_off[id] = off;
-        for (size_t i = 0; i < nd.nbr[0].size(); ++i) nbr0[(size_t)id * max0 + i] = (uint32_t)nd.nbr[0][i];
+        for (size_t i = 0; i < nd.nbr[0].size(); ++i) { nbr0[(size_t)id * max0 + i] = (uint32_t)nd.nbr[0][i]; nbr0_row[(size_t)id * max0 + i] = row_now(nd.nbr[0][i]); }
         for (size_t l = 1; l < nd.nbr.size(); ++l) {
             cntU[off + l - 1] = (uint32_t)nd.nbr[l].size();
-            for (size_t i = 0; i < nd.nbr[l].size(); ++i) nbrU[(size_t)(off + l - 1) * maxU + i] = (uint32_t)nd.nbr[l][i];
+            for (size_t i = 0; i < nd.nbr[l].size(); ++i) { nbrU[(size_t)(off + l - 1) * maxU + i] = (uint32_t)nd.nbr[l][i]; nbrU_row[(size_t)(off + l - 1) * maxU + i] = row_now(nd.nbr[l][i]); }
         }
         off += nd.level;
     }
-    for (uint32_t** p : {&g->d_row_of, &g->d_level, &g->d_nbr0, &g->d_cnt0, &g->d_up_off, &g->d_nbrU, &g->d_cntU})
+    for (uint32_t** p : {&g->d_row_of, &g->d_level, &g->d_nbr0, &g->d_cnt0, &g->d_up_off, &g->d_nbrU, &g->d_cntU, &g->d_nbr0_row, &g->d_nbrU_row})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     auto up = [&](uint32_t** dst, const std::vector<uint32_t>& v) -> int {
         HN_TRY(hipMalloc((void**)dst, std::max<size_t>(v.size(), 1) * 4));
@@ -552,7 +555,8 @@ int upload_mirror(vdb_hnsw_index* g, hipStream_t s) {
     };
     int rc;
     if ((rc = up(&g->d_row_of, row_of)) || (rc = up(&g->d_level, level)) || (rc = up(&g->d_nbr0, nbr0)) || (rc = up(&g->d_cnt0, cnt0)) ||
-        (rc = up(&g->d_up_off, up_off)) || (rc = up(&g->d_nbrU, nbrU)) || (rc = up(&g->d_cntU, cntU)))
+        (rc = up(&g->d_up_off, up_off)) || (rc = up(&g->d_nbrU, nbrU)) || (rc = up(&g->d_cntU, cntU)) ||
+        (rc = up(&g->d_nbr0_row, nbr0_row)) || (rc = up(&g->d_nbrU_row, nbrU_row)))
         return rc;
     HN_TRY(hipStreamSynchronize(s));                                   // the staging vectors go out of scope
     g->mirror_ids = n; g->stride0 = max0; g->strideU = maxU; g->max_list = std::max(max0, maxU);
@@ -586,8 +590,8 @@ int search_device(vdb_hnsw_index* g, const float* queries, size_t nq, size_t dim
     HN_TRY(hipMemsetAsync(dv.status, 0, 16, s));
     vdb::HnswSearchParams hp{};
     hp.rows = dv.rows; hp.ld = dv.ld; hp.dim = dv.dim; hp.nd = dv.nd; hp.metric = dv.metric; hp.qp = dv.qp; hp.qnorm = dv.qnorm;
-    hp.row_of = g->d_row_of; hp.level = g->d_level; hp.n_ids = g->mirror_ids; hp.nbr0 = g->d_nbr0; hp.cnt0 = g->d_cnt0; hp.stride0 = g->stride0;
-    hp.up_off = g->d_up_off; hp.nbrU = g->d_nbrU; hp.cntU = g->d_cntU; hp.strideU = g->strideU;
+    hp.row_of = g->d_row_of; hp.level = g->d_level; hp.n_ids = g->mirror_ids; hp.nbr0 = g->d_nbr0; hp.nbr0_row = g->d_nbr0_row; hp.cnt0 = g->d_cnt0;
+    hp.stride0 = g->stride0; hp.up_off = g->d_up_off; hp.nbrU = g->d_nbrU; hp.nbrU_row = g->d_nbrU_row; hp.cntU = g->d_cntU; hp.strideU = g->strideU;
     hp.entry_point = (uint32_t)g->ep; hp.max_level = (uint32_t)g->max_level; hp.ef = (uint32_t)ef_actual; hp.k = (uint32_t)k;
     hp.out_ids = g->d_out_ids; hp.out_dists = g->d_out_dists; hp.out_counts = g->d_out_counts; hp.fail = g->d_fail; hp.status = dv.status;
     vdb::launch_hnsw_search(hp, (uint32_t)nq, s);
