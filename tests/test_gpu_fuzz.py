@@ -17,3 +17,10 @@ def test_random_configurations_are_bit_identical_to_the_oracle():
                           "--max-rows", "150000"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "ALL 16 CASES OK" in out.stdout
+
+
+def test_random_hnsw_configurations_equal_the_cpu_restatement():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_hnsw.py"), "--cases", "10", "--seed", "4"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "ALL 10 HNSW CASES OK" in out.stdout
