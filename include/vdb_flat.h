@@ -192,6 +192,7 @@ int vdb_flat_last_stats(const vdb_flat_index *h, uint64_t out[8]);
  *  [10] [11] [12] host clock of the call, ns: first tier enqueued / its flags on the host / return
  *  [13] queries answered by the re-threshold pass (a second screening pass whose thresholds are the score cuts that the
  *       k-th exact distances of the first pass imply; every key under the cut is re-ranked)
+ *  [14] 1 when the screening pass read the bf16 shadow copy of the rows (vdb_flat_set_shadow)
  * With the screening tier on, [4] [5] [7] describe ITS sample, k' and kernel time. */
 int vdb_flat_last_stats_ex(const vdb_flat_index *h, uint64_t *out, size_t n);
 
@@ -202,6 +203,16 @@ int vdb_flat_last_stats_ex(const vdb_flat_index *h, uint64_t *out, size_t n);
  *  0: the f32-input MFMA tier only (v_mfma_f32_32x32x2_f32, arithmetic-bound), then the exact scan.
  * The environment variable VDB_SCREEN=f32 selects 0 for every handle created afterwards. */
 int vdb_flat_set_screen(vdb_flat_index *h, int mode);
+
+/* Opt-in bf16 SHADOW COPY of the rows for the screening tier (no reference counterpart; results are identical either
+ * way).  on = 1 keeps, next to the f32 rows, their bf16 rounding (2 more bytes per element of HBM: +50 %); the screening
+ * pass then streams the shadow -- half the bytes of the HBM-bound pass -- and computes exactly the scores it computes
+ * from the f32 rows (the same RNE conversion, done once at upload instead of in the kernel).  The exact re-rank, the
+ * certificates and every fallback tier keep reading the f32 rows.  Existing rows are converted by the call, later adds
+ * maintain the shadow; on = 0 frees it.  VDB_SHADOW=1 turns it on for every handle created afterwards.  Rows of fewer
+ * than 33 dimensions are always screened from the f32 rows.  vdb_flat_last_stats_ex()[14] = 1 when the last search
+ * screened from the shadow. */
+int vdb_flat_set_shadow(vdb_flat_index *h, int on);
 
 /* Thread-local message of the last failing call on this thread, plus the
  * DimensionMismatch pair (error.rs:12-13).  Any pointer may be NULL. */

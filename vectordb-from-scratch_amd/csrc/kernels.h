@@ -70,6 +70,8 @@ struct RowStatsParams {
                              // row, as f32 bits of |x - bf16(x)|^2 (slot 2) and of |x - bf16(x)|^2 / |x|^2 (slot 3)
 };
 void launch_row_stats(const RowStatsParams& p, hipStream_t s);
+// bf16 shadow of rows [row_begin, row_end): v_cvt_pk_bf16_f32 (RNE) of every element of the padded row
+void launch_rows_to_bf16(const float* rows, uint16_t* rows16, uint32_t ld, uint32_t row_begin, uint32_t row_end, hipStream_t s);
 
 // count live rows whose norm is exactly zero (Cosine: distance.rs:51-55)
 void launch_count_zero_live(const float* nd, const uint32_t* livemask, uint32_t n_rows,
@@ -151,6 +153,7 @@ void launch_fused_dma3(const FusedParams& p, uint32_t n_super, hipStream_t s);
 // ---------------------------------------------------------------- bf16 screening tier (kernels_fused_bf16.hip)
 struct FusedBf16Params {
     const float* rows; uint32_t ld; uint32_t n_rows;
+    const uint16_t* rows16;                            // bf16 shadow of `rows` [n_rows][ld] (kernels_fused_a16.hip only; ld >= 64)
     const uint16_t* qb;                                // [256][ld] bf16 queries of this pass (zero padded)
     const float* alpha; const float* beta;
     const uint32_t* rowmask;                           // NEVER null: the live mask when there is no filter
@@ -166,6 +169,8 @@ struct FusedBf16Params {
 };
 void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s);
 void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s);
+void launch_fused_a16(const FusedBf16Params& p, hipStream_t s);      // the same kernels reading p.rows16
+void launch_sample_a16(const FusedBf16Params& p, hipStream_t s);
 uint32_t fused_bf16_tile_rows();
 uint32_t fused_bf16_subpools_per_query(uint32_t n_wg);
 uint32_t fused_bf16_sample_groups(uint32_t n_sample);

@@ -1,0 +1,422 @@
+// kernels_fused_a16.hip -- the screening kernel of kernels_fused_bf16.hip reading a bf16 SHADOW COPY of the rows
+// (vdb_flat_set_shadow: +2 bytes per element of HBM, opt-in) instead of the f32 rows: half the bytes per pass.  The
+// shadow is the RNE rounding of the f32 rows (v_cvt_pk_bf16_f32 at upload) -- exactly what the f32-row kernel computes in
+// registers -- so scores, candidates, certificates and results are bit-identical to that kernel's; only the bytes differ.
+//
+// A stage is 32 K-elements of 256 rows (bf16, 16 KB) and of 256 queries (bf16, 16 KB); FOUR 32 KB images form the
+// LDS ring, so three stages are in flight (the f32-row kernel: three 48 KB images, two in flight).  The wave waits with
+// `s_waitcnt vmcnt(8)` (the 2 x 4 pieces of stages s+1 and s+2 may be outstanding) before the barrier that publishes
+// stage s, then issues stage s+3 into the image stage s-1 just left.  Fragments are read from LDS as bf16 (one
+// ds_read_b128 each, no conversion in the loop).  Everything else -- tile shape, wave layout, constants by LDS-DMA,
+// epilogue, sample mode -- is the f32-row kernel's.
+#include "kernels.h"
+
+#include <type_traits>
+
+namespace vdb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int NW = 8, NT = NW * 64;
+constexpr int TR = 256;                          // rows per tile
+constexpr int TQ = 256;                          // queries per tile
+constexpr int A_ROWB = 64;                       // 32 bf16 per row and stage
+constexpr int B_ROWB = 64;                       // 32 bf16 per query and stage
+constexpr int A_BYTES = TR * A_ROWB;             // 16 KB
+constexpr int B_BYTES = TQ * B_ROWB;             // 16 KB
+constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 32 KB
+constexpr int MT = 4, QT = 2;                    // MFMA tiles per wave: 4 x 32 rows, 2 x 32 queries
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+}  // namespace
+
+template <bool SAMPLE>
+__global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
+    // four DISTINCT LDS objects, each access names its image at compile time
+    __shared__ __attribute__((aligned(16))) char sImg0[STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char sImg1[STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char sImg2[STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char sImg3[STAGE_BYTES];
+    // per-row constants of a tile (alpha, beta, the row's eligibility-mask word), double buffered by tile parity;
+    // filled by LDS-DMA as well, so that no wave ever holds a pending ordinary load inside the stage loop
+    __shared__ __attribute__((aligned(16))) float sAlpha[2 * TR];
+    __shared__ __attribute__((aligned(16))) float sBeta[2 * TR];
+    __shared__ __attribute__((aligned(16))) uint32_t sMaskW[2 * TR];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wr = w >> 2, wq = w & 3;                             // row half, query quarter of this wave
+    const uint32_t c = lane & 31, h = lane >> 5;
+    const uint32_t ld = p.ld;
+    const uint32_t KS = ld / KSTAGE;
+
+    // ---- the rows this workgroup covers
+    // (sample mode: exactly ONE tile per workgroup, grid = number of sample tiles.  A compile-time tile count lets
+    // the compiler drop the next-tile address state; with it the sample instance spilled registers to scratch, and
+    // every scratch reload put a vmcnt(0) -- a full drain of the DMA pipeline -- into the stage loop)
+    uint32_t r0 = 0, r1 = 0, ntiles_rt = 0;
+    const uint32_t tile_first = SAMPLE ? blockIdx.x : 0u;
+    constexpr uint32_t tile_step = 0;
+    if (SAMPLE) {
+        ntiles_rt = 1;
+    } else {
+        // row ranges in WHOLE tiles: a range of 15.26 tiles costs 16 tile iterations whatever its last tile holds, so
+        // the tiles are dealt out whole -- some workgroups run one tile fewer, and the last tiles of the others meet
+        // an HBM that is no longer contended
+        const uint32_t nblk = (p.n_rows + TR - 1) / TR;
+        const uint32_t b0 = (uint32_t)(((uint64_t)blockIdx.x * nblk) / p.n_wg);
+        const uint32_t b1 = (uint32_t)(((uint64_t)(blockIdx.x + 1) * nblk) / p.n_wg);
+        r0 = b0 * TR;
+        r1 = (b1 * TR < p.n_rows) ? b1 * TR : p.n_rows;
+        ntiles_rt = r0 < r1 ? (r1 - r0 + TR - 1) / TR : 0;
+    }
+    const uint32_t ntiles = SAMPLE ? 1u : ntiles_rt;
+    // queries of this lane: one column in each of the wave's two 32-query MFMA tiles
+    const uint32_t q_a = wq * 64 + c, q_b = q_a + 32;
+    uint64_t* pool_a = nullptr; uint64_t* pool_b = nullptr;
+    size_t sub_a = 0, sub_b = 0;
+    float thr_a = 0.f, thr_b = 0.f;
+    if (!SAMPLE) {
+        sub_a = (((size_t)q_a * p.n_wg + blockIdx.x) * 2 + wr) * 2 + h;
+        sub_b = (((size_t)q_b * p.n_wg + blockIdx.x) * 2 + wr) * 2 + h;
+        pool_a = p.pool + sub_a * p.capl;
+        pool_b = p.pool + sub_b * p.capl;
+        thr_a = p.thr[q_a];
+        thr_b = p.thr[q_b];
+        // consume the two loads here: a first use inside the stage loop would get a compiler-inserted vmcnt(0)
+        // there, i.e. a wait for every DMA in flight, once per tile
+        asm volatile("" : "+v"(thr_a), "+v"(thr_b));
+    }
+    uint32_t pcnt_a = 0, pcnt_b = 0;
+    if (ntiles == 0) {
+        if (!SAMPLE) { p.pool_cnt[sub_a] = 0; p.pool_cnt[sub_b] = 0; }
+        return;
+    }
+    const uint32_t total = ntiles * KS;
+    const uint32_t last_row = p.n_rows - 1;
+    // sample index -> device row.  The S sample positions are spread evenly over the rows ((pos * n) >> shift), and
+    // CONSECUTIVE positions go to DIFFERENT tiles (index j = tile*256 + tile-row sits at position tile-row*tiles + tile):
+    // when near neighbours are stored next to each other (data ordered by cluster) their sample rows then land in
+    // different groups, each contributes its own group minimum, and the threshold stays as tight as on shuffled data
+    // (with consecutive positions in one tile a 500-row cluster was represented by 4 minima, the threshold came from far
+    // rows and thousands of keys overflowed the pools).  Block mode (sample_block != 0, diagnostics): tiles of
+    // contiguous rows.
+    auto sample_row_of = [&](uint32_t j) -> uint32_t {
+        if (p.sample_block) return (j >> 8) * p.sample_block + (j & 255u);
+        const uint32_t pos = (j & 255u) * (p.n_sample >> 8) + (j >> 8);
+        return (uint32_t)(((uint64_t)pos * p.n_rows) >> p.sample_shift);
+    };
+    const char* __restrict__ rows_b = reinterpret_cast<const char*>(p.rows16);
+    const char* __restrict__ bbase = reinterpret_cast<const char*>(p.qb);
+
+    // ---- DMA plan.  A stage image = 16 row pieces + 16 query pieces of 1 KB.  Wave w fills row pieces
+    // 2w, 2w+1 (16 rows x 64 B each: lane L -> row L>>2, 16-byte position L&3) and query pieces 2w, 2w+1
+    // (16 queries x 64 B each, same shape).  Both images are XOR-swizzled so that the fragment reads below are
+    // bank-conflict free: data chunk x of row/query r sits at position x ^ ((r>>2)&3); the filling lane fetches the
+    // permuted source chunk.
+    const uint32_t a_pr = lane >> 2, a_pp = lane & 3;
+    const uint32_t b_pr = lane >> 2, b_pp = lane & 3;
+    uint32_t a_chunk[2];                                                // source byte offset inside the 64-B stage
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t rt = 32 * w + 16 * j + a_pr;                     // row inside the tile
+        a_chunk[j] = (a_pp ^ ((rt >> 2) & 3)) * 16;
+    }
+    // (the queries are stored by query_prep in exactly this image order, one 16 KB image per K stage: a wave's
+    // query piece is 1 KB of CONTIGUOUS global memory -- 8 full 128-byte requests instead of 16 scattered 64-byte ones)
+    const uint32_t ob[2] = {(2 * w) * 1024 + lane * 16, (2 * w + 1) * 1024 + lane * 16};
+    (void)b_pr; (void)b_pp;
+    const char* aptr[2];                                                // row pieces of the tile being fetched
+    auto tile_rows_of = [&](uint32_t t, uint32_t rt) -> uint32_t {      // device row of tile-row rt of local tile t
+        if (SAMPLE) {
+            uint32_t j = (tile_first + t * tile_step) * TR + rt;
+            if (j >= p.n_sample) j = p.n_sample - 1;
+            return sample_row_of(j);                                   // n_sample = 2^sample_shift <= n_rows
+        } else {
+            const uint32_t r = r0 + t * TR + rt;
+            return r > last_row ? last_row : r;
+        }
+    };
+    auto set_tile_ptrs = [&](uint32_t t) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t row = tile_rows_of(t, 32 * w + 16 * j + a_pr);
+            aptr[j] = rows_b + (size_t)row * ld * 2 + a_chunk[j];
+        }
+    };
+    // The LDS-DMA is issued from inline asm, not through __builtin_amdgcn_global_load_lds: hipcc's waitcnt pass
+    // tracks the builtin as a pending LDS write and, at the loop header of the 3-stage ring, cannot bound how many
+    // vector-memory operations followed the fill of the image about to be read -- it then puts a vmcnt(0) in front
+    // of that stage's first ds_read, which drains the two-stage DMA pipeline.  All ordering between the DMA and the
+    // LDS reads is done by hand here (counted s_waitcnt + s_barrier at the top of each stage); compiler-inserted
+    // vmcnt waits for ordinary loads stay correct because not counting these instructions only makes them wait longer.
+#define VDB_DMA(GP, IMG, LOFF)                                                                         \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"                     \
+                 :: "s"((uint32_t)(uintptr_t)(lds_ptr_t)((IMG) + (LOFF))), "v"((const void*)(GP)) : "memory", "m0")
+    // rows are read once per launch: non-temporal, so that they do not push the queries out of the L2
+#define VDB_DMA_NT(GP, IMG, LOFF)                                                                      \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt"                  \
+                 :: "s"((uint32_t)(uintptr_t)(lds_ptr_t)((IMG) + (LOFF))), "v"((const void*)(GP)) : "memory", "m0")
+#define VDB_ISSUE(IMG, KSI)                                                                            \
+    {                                                                                                  \
+        const uint32_t la_ = (2 * w) * 1024;                                                           \
+        const uint32_t lb_ = A_BYTES + (2 * w) * 1024;                                                 \
+        const uint32_t ka_ = (KSI) * (KSTAGE * 2);                                                     \
+        const uint32_t kb_ = (KSI) * B_BYTES;                                                          \
+        if (!(p.ablate & 2u)) {                                                                        \
+        VDB_DMA_NT(aptr[0] + ka_, IMG, la_);                                                           \
+        VDB_DMA_NT(aptr[1] + ka_, IMG, la_ + 1024);                                                    \
+        }                                                                                              \
+        if (!(p.ablate & 4u)) {                                                                        \
+        VDB_DMA(bbase + (ob[0] + kb_), IMG, lb_);                                                      \
+        VDB_DMA(bbase + (ob[1] + kb_), IMG, lb_ + 1024);                                               \
+        }                                                                                              \
+    }
+
+    // ---- row constants of a tile, one tile ahead, by LDS-DMA (4 bytes per lane): waves 0-3 fetch alpha and the mask
+    // word of rows 64(w&3)..+63, waves 4-7 fetch beta.  Issued BEFORE the stage's row/query pieces, so the counted
+    // wait at the top of the next stage covers them.
+#define VDB_DMA4(GP, LP)                                                                               \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"                        \
+                 :: "s"((uint32_t)(uintptr_t)(lds_ptr_t)(LP)), "v"((const void*)(GP)) : "memory", "m0")
+    auto issue_consts = [&](uint32_t t) {
+        const uint32_t par = t & 1u;
+        const uint32_t cr = 64 * (w & 3);                              // first tile-row of this wave's chunk
+        const uint32_t row = tile_rows_of(t, cr + lane);
+        if (w < 4) {
+            VDB_DMA4(p.alpha + row, sAlpha + par * TR + cr);
+            VDB_DMA4(p.rowmask + (row >> 5), sMaskW + par * TR + cr);
+        } else {
+            VDB_DMA4(p.beta + row, sBeta + par * TR + cr);
+        }
+    };
+
+    f32x16 acc[MT][QT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < QT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // fragment read offsets (bytes inside an image)
+    const uint32_t swa = (c >> 2) & 3, swb = (c >> 2) & 3;
+    const uint32_t a_row_off = (wr * 128 + c) * A_ROWB;                 // + i*32*A_ROWB
+    const uint32_t b_row_off = A_BYTES + (wq * 64 + c) * B_ROWB;        // + j*32*B_ROWB
+    uint32_t ra[2], rb[2];                                              // [k-step]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        ra[t] = ((2 * t + h) ^ swa) * 16;
+        rb[t] = ((2 * t + h) ^ swb) * 16;
+    }
+
+    // ---- prologue: constants of tile 0 and stages 0, 1 and 2 in flight
+    uint32_t tile = 0, ks = 0;                                          // of the stage being computed
+    uint32_t ftile = 0, fks = 0;                                        // of the next stage to fetch
+    set_tile_ptrs(0);
+    issue_consts(0);
+    VDB_ISSUE(sImg0, 0u)
+    fks = 1;
+    if (fks == KS) { fks = 0; ftile = 1; if (ftile < ntiles) set_tile_ptrs(ftile); }
+    if (total > 1) {
+        VDB_ISSUE(sImg1, fks)
+        ++fks;
+        if (fks == KS) { fks = 0; ++ftile; if (ftile < ntiles) set_tile_ptrs(ftile); }
+    }
+    if (total > 2) {
+        VDB_ISSUE(sImg2, fks)
+        ++fks;
+        if (fks == KS) { fks = 0; ++ftile; if (ftile < ntiles) set_tile_ptrs(ftile); }
+    }
+
+    // STEADY: the caller guarantees st + 3 < total, so the wait and the DMA issue are unconditional (see the f32-row
+    // kernel for why that matters to hipcc's waitcnt pass).
+    auto run_stage = [&](uint32_t st, auto buf_tag, auto steady_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const char* img = BUF == 0 ? sImg0 : BUF == 1 ? sImg1 : BUF == 2 ? sImg2 : sImg3;
+        char* img_fill = BUF == 0 ? sImg3 : BUF == 1 ? sImg0 : BUF == 2 ? sImg1 : sImg2;   // stage st+3 goes where stage st-1 was
+        // publish stage st: this wave's pieces have landed once at most the 2 x 4 pieces of stages st+1, st+2 are outstanding
+        // (a bare s_barrier: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), which would drain the
+        // DMA pipeline at every stage; LDS writes are waited for explicitly, and the asm memory clobbers keep
+        // the compiler from moving LDS accesses across)
+        if (STEADY || st + 2 < total) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (st + 1 < total) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // constants of the NEXT tile into the other parity (every wave is past the epilogue that read it)
+        if (ks == 0 && tile + 1 < ntiles) issue_consts(tile + 1);
+        if (STEADY || st + 3 < total) {
+            VDB_ISSUE(img_fill, fks)
+            ++fks;
+            if (fks == KS) { fks = 0; ++ftile; if (ftile < ntiles) set_tile_ptrs(ftile); }
+        }
+        // ---- 2 k-steps of 16: fragments -> bf16 -> 8 MFMAs each
+        const char* ap = img + a_row_off;
+        const char* bp = img + b_row_off;
+        if (!(p.ablate & 1u))
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bf16x8 fa[MT], fb[QT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(ap + i * 32 * A_ROWB + ra[t]);
+                fa[i] = __builtin_bit_cast(bf16x8, raw);
+            }
+#pragma unroll
+            for (int j = 0; j < QT; ++j) {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(bp + j * 32 * B_ROWB + rb[t]);
+                fb[j] = __builtin_bit_cast(bf16x8, raw);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < QT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+
+        if (ks == KS - 1 && !(p.ablate & 8u)) {
+            const uint32_t par = tile & 1u;
+            // (the constants of this tile were issued at least two K stages ago -- the launcher requires ld >= 64 -- and
+            // before the pieces of a stage whose top-of-stage wait has already been passed, so they have landed)
+            uint32_t tr0;                                               // device row of tile-row 0 (filter mode)
+            uint32_t sj0 = 0;                                           // sample index of tile-row 0 (sample mode)
+            if (SAMPLE) { sj0 = (tile_first + tile * tile_step) * TR; tr0 = 0; }
+            else tr0 = r0 + tile * TR;
+            // eligibility of this wave's 128 rows: two ballots over (in range) & (mask bit of the row)
+            unsigned long long val[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const uint32_t rt = wr * 128 + 64 * m + lane;
+                bool in;
+                uint32_t bit;
+                if (SAMPLE) {
+                    const uint32_t sj = sj0 + rt;
+                    in = sj < p.n_sample;
+                    const uint32_t row = sample_row_of(sj);
+                    bit = row & 31;
+                } else {
+                    in = tr0 + rt < r1;
+                    bit = rt & 31;                                      // tr0 is a multiple of 32
+                }
+                val[m] = __ballot(in && ((sMaskW[par * TR + rt] >> bit) & 1u));
+            }
+            float best_a = __uint_as_float(0x7f800000u), best_b = best_a;   // sample mode: running group minima
+            const float* al = sAlpha + par * TR + wr * 128 + 4 * h;
+            const float* be = sBeta + par * TR + wr * 128 + 4 * h;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const uint32_t vbits = (uint32_t)(val[i >> 1] >> (32 * (i & 1) + 4 * h));
+                const uint32_t rowb = wr * 128 + i * 32 + 4 * h;       // tile-row of element (j = 0, e = 0)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(al + i * 32 + 8 * j);
+                    const float4 b4 = *reinterpret_cast<const float4*>(be + i * 32 + 8 * j);
+                    // scores of 4 rows x 2 queries
+                    const float sa0 = fmaf(acc[i][0][4 * j + 0], a4.x, b4.x), sa1 = fmaf(acc[i][0][4 * j + 1], a4.y, b4.y);
+                    const float sa2 = fmaf(acc[i][0][4 * j + 2], a4.z, b4.z), sa3 = fmaf(acc[i][0][4 * j + 3], a4.w, b4.w);
+                    const float sb0 = fmaf(acc[i][1][4 * j + 0], a4.x, b4.x), sb1 = fmaf(acc[i][1][4 * j + 1], a4.y, b4.y);
+                    const float sb2 = fmaf(acc[i][1][4 * j + 2], a4.z, b4.z), sb3 = fmaf(acc[i][1][4 * j + 3], a4.w, b4.w);
+                    const uint32_t rt0 = rowb + 8 * j;                  // tile-row of element 0
+                    if (SAMPLE) {
+                        // smallest score of the lane's eligible rows (v_min_f32 skips a NaN score: such a row is no witness
+                        // for a threshold, and it reaches the re-rank through the filter pass, which keeps NaN scores)
+                        const float inf_ = __uint_as_float(0x7f800000u);
+#define VDB_MIN(E, SA, SB)                                                                             \
+    {                                                                                                  \
+        const bool ok_ = (vbits >> (8 * j + (E))) & 1u;                                                \
+        best_a = fminf(best_a, ok_ ? (SA) : inf_);                                                     \
+        best_b = fminf(best_b, ok_ ? (SB) : inf_);                                                     \
+    }
+                        VDB_MIN(0, sa0, sb0) VDB_MIN(1, sa1, sb1) VDB_MIN(2, sa2, sb2) VDB_MIN(3, sa3, sb3)
+#undef VDB_MIN
+                    } else {
+                        // Hits are rare (about 0.2 % of the elements).  Common path per query: four compares whose
+                        // lane masks are OR-ed on the scalar unit and ONE not-taken branch; the append code is out of
+                        // line.  `!(s > thr)` keeps a NaN score (it must reach the re-rank, flat_index.rs:62).
+                        const unsigned long long ma = __builtin_amdgcn_ballot_w64(!(sa0 > thr_a)) | __builtin_amdgcn_ballot_w64(!(sa1 > thr_a)) |
+                                                      __builtin_amdgcn_ballot_w64(!(sa2 > thr_a)) | __builtin_amdgcn_ballot_w64(!(sa3 > thr_a));
+                        const unsigned long long mb = __builtin_amdgcn_ballot_w64(!(sb0 > thr_b)) | __builtin_amdgcn_ballot_w64(!(sb1 > thr_b)) |
+                                                      __builtin_amdgcn_ballot_w64(!(sb2 > thr_b)) | __builtin_amdgcn_ballot_w64(!(sb3 > thr_b));
+#define VDB_PUSH(E, S, THR, POOL, PCNT)                                                                \
+    if (!((S) > (THR)) && ((vbits >> (8 * j + (E))) & 1u)) {                                           \
+        if (PCNT < p.capl) POOL[PCNT] = make_raw_key((S), tr0 + rt0 + (E));                            \
+        ++PCNT;                                                                                        \
+    }
+                        if (__builtin_expect(ma != 0ull, 0)) {
+                            VDB_PUSH(0, sa0, thr_a, pool_a, pcnt_a) VDB_PUSH(1, sa1, thr_a, pool_a, pcnt_a)
+                            VDB_PUSH(2, sa2, thr_a, pool_a, pcnt_a) VDB_PUSH(3, sa3, thr_a, pool_a, pcnt_a)
+                        }
+                        if (__builtin_expect(mb != 0ull, 0)) {
+                            VDB_PUSH(0, sb0, thr_b, pool_b, pcnt_b) VDB_PUSH(1, sb1, thr_b, pool_b, pcnt_b)
+                            VDB_PUSH(2, sb2, thr_b, pool_b, pcnt_b) VDB_PUSH(3, sb3, thr_b, pool_b, pcnt_b)
+                        }
+#undef VDB_PUSH
+                    }
+                }
+            }
+            if (SAMPLE) {
+                // one group minimum per (tile, row half, lane half) and query
+                const uint32_t g = (((tile_first + tile * tile_step) * 2 + wr) * 2 + h);
+                // the key's low word only has to make the keys of one query distinct: the group index
+                p.minkeys[(size_t)q_a * p.minkey_stride + g] = best_a < __uint_as_float(0x7f800000u) ? make_key(best_a, g) : EMPTY_KEY;
+                p.minkeys[(size_t)q_b * p.minkey_stride + g] = best_b < __uint_as_float(0x7f800000u) ? make_key(best_b, g) : EMPTY_KEY;
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < QT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        }
+        ++ks;
+        if (ks == KS) { ks = 0; ++tile; }
+    };
+
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using B2 = std::integral_constant<int, 2>;
+    using B3 = std::integral_constant<int, 3>;
+    uint32_t st = 0;
+    for (; st + 6 < total; st += 4) {                                   // stage index mod 4 == image index
+        run_stage(st, B0{}, std::true_type{});
+        run_stage(st + 1, B1{}, std::true_type{});
+        run_stage(st + 2, B2{}, std::true_type{});
+        run_stage(st + 3, B3{}, std::true_type{});
+    }
+    // the last one to six stages: conditional issue
+    if (st < total) { run_stage(st, B0{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, B1{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, B2{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, B3{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, B0{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, B1{}, std::false_type{}); ++st; }
+    if (!SAMPLE) {
+        p.pool_cnt[sub_a] = pcnt_a;
+        p.pool_cnt[sub_b] = pcnt_b;
+    }
+#undef VDB_DMA
+#undef VDB_DMA_NT
+#undef VDB_DMA4
+#undef VDB_ISSUE
+}
+
+// same tile shape, sub-pool and sample-group layout as the f32-row kernel (fused_bf16_tile_rows & co.)
+void launch_fused_a16(const FusedBf16Params& p, hipStream_t s) {
+    hipLaunchKernelGGL(fused_a16_kernel<false>, dim3(p.n_wg), dim3(NT), 0, s, p);
+}
+void launch_sample_a16(const FusedBf16Params& p, hipStream_t s) {
+    const uint32_t stiles = (p.n_sample + TR - 1) / TR;
+    if (!stiles) return;
+    hipLaunchKernelGGL(fused_a16_kernel<true>, dim3(stiles), dim3(NT), 0, s, p);
+}
+
+}  // namespace vdb

@@ -116,6 +116,8 @@ struct vdb_flat_index {
     bool live_dirty = false;
 
     // device store
+    uint16_t* d_rows16 = nullptr;         // opt-in bf16 shadow of d_rows [cap_rows][ld] (vdb_flat_set_shadow), else null
+    bool shadow = false;
     float* d_rows = nullptr; float* d_nd = nullptr; float* d_alpha = nullptr; float* d_beta = nullptr;
     uint64_t* d_row_ids = nullptr; uint32_t* d_live = nullptr; uint32_t* d_scalars = nullptr;  // [0]=nd2max bits [1]=zero count [2],[3]=max bf16 rounding error of a row (abs^2, rel^2)
     uint32_t cap_rows = 0;
@@ -184,6 +186,12 @@ int grow(Index* ix, uint32_t need_rows) {
     HIP_TRY(hipMalloc((void**)&lv, (size_t)cap / 8));
     hipStream_t s = ix->stream;
     uint32_t old = ix->n_uploaded;
+    uint16_t* r16 = nullptr;
+    if (ix->shadow) {
+        HIP_TRY(hipMalloc((void**)&r16, (size_t)cap * ix->ld * 2));
+        if (old && ix->d_rows16) HIP_TRY(hipMemcpyAsync(r16, ix->d_rows16, (size_t)old * ix->ld * 2, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemsetAsync((char*)r16 + (size_t)old * ix->ld * 2, 0, (size_t)(cap - old) * ix->ld * 2, s));
+    }
     if (old) {
         HIP_TRY(hipMemcpyAsync(rows, ix->d_rows, (size_t)old * row_bytes, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(nd, ix->d_nd, (size_t)old * 4, hipMemcpyDeviceToDevice, s));
@@ -199,6 +207,8 @@ int grow(Index* ix, uint32_t need_rows) {
         (void)hipFree(ix->d_rows); (void)hipFree(ix->d_nd); (void)hipFree(ix->d_alpha);
         (void)hipFree(ix->d_beta); (void)hipFree(ix->d_row_ids); (void)hipFree(ix->d_live);
     }
+    if (ix->d_rows16) (void)hipFree(ix->d_rows16);
+    ix->d_rows16 = r16;
     ix->d_rows = rows; ix->d_nd = nd; ix->d_alpha = al; ix->d_beta = be; ix->d_row_ids = ids; ix->d_live = lv;
     ix->cap_rows = cap;
     ix->live_dirty = true;
@@ -210,6 +220,8 @@ void free_store(Index* ix) {
         (void)hipFree(ix->d_rows); (void)hipFree(ix->d_nd); (void)hipFree(ix->d_alpha);
         (void)hipFree(ix->d_beta); (void)hipFree(ix->d_row_ids); (void)hipFree(ix->d_live);
     }
+    if (ix->d_rows16) (void)hipFree(ix->d_rows16);
+    ix->d_rows16 = nullptr;
     ix->d_rows = ix->d_nd = ix->d_alpha = ix->d_beta = nullptr;
     ix->d_row_ids = nullptr; ix->d_live = nullptr;
     ix->cap_rows = 0;
@@ -314,6 +326,7 @@ int flush(Index* ix) {
         vdb::RowStatsParams rp{ix->d_rows, ix->ld, ix->dim, first, n, ix->metric, ix->d_nd, ix->d_alpha,
                                ix->d_beta, ix->d_scalars};
         vdb::launch_row_stats(rp, s);
+        if (ix->d_rows16) vdb::launch_rows_to_bf16(ix->d_rows, ix->d_rows16, ix->ld, first, n, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(s));   // pending is host memory about to be released
         ix->pending.clear();
@@ -583,12 +596,16 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         const uint32_t nb = std::min(SUPER, nq - q0);
         vdb::FusedBf16Params fp{};
         fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w_qb.p + (size_t)q0 * ld;
+        fp.rows16 = ix->d_rows16;
+        const bool a16 = ix->d_rows16 && ld >= 64;             // the shadow kernel's constant prefetch needs two K stages per row
+        ix->stats[14] = a16;
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
         fp.thr = ix->w_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
         fp.ablate = getenv("VDB_BF16_ABLATE") ? (uint32_t)atoi(getenv("VDB_BF16_ABLATE")) : 0u;
         fp.n_sample = S; fp.sample_shift = pl.shift;
         fp.sample_block = getenv("VDB_SAMPLE_BLOCK") ? (n / (S / 256u)) : 0u; fp.minkeys = ix->w_dense.p; fp.minkey_stride = M;
-        vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);
+        if (a16) vdb::launch_sample_a16(fp, s);
+        else vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);
 
         vdb::SelectParams sp{};
         sp.keys = ix->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = KT;
@@ -596,7 +613,8 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         vdb::launch_select(sp, nb, s);
 
         if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
-        vdb::launch_fused_bf16(fp, s);
+        if (a16) vdb::launch_fused_a16(fp, s);
+        else vdb::launch_fused_bf16(fp, s);
         if (ix->profile) {
             HIP_TRY(hipEventRecord(ix->ev1, s));
             HIP_TRY(hipEventSynchronize(ix->ev1));
@@ -674,9 +692,11 @@ int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo
         const uint32_t nb = std::min(SUPER, nf - q0);
         vdb::FusedBf16Params fp{};
         fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w2_qb.p + (size_t)q0 * ld;
+        fp.rows16 = ix->d_rows16;
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
         fp.thr = ix->w2_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
-        vdb::launch_fused_bf16(fp, s);
+        if (ix->d_rows16 && ld >= 64) vdb::launch_fused_a16(fp, s);
+        else vdb::launch_fused_bf16(fp, s);
         ix->stats[3] += n;
         vdb::SelectParams mp{};
         mp.keys = ix->w_pool.p; mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl;
@@ -1049,6 +1069,7 @@ int vdb_flat_create(int metric, int device, vdb_flat_index** out) {
     ix->device = device;
     ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("VDB_SCREEN")) ix->screen = strcmp(e, "f32") != 0 && strcmp(e, "0") != 0;
+    if (const char* e = getenv("VDB_SHADOW")) ix->shadow = strcmp(e, "0") != 0;
     if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ix;
         return fail(VDB_ERR_DEVICE, "hipStreamCreate failed");
@@ -1158,6 +1179,7 @@ int vdb_flat_add_bulk_device(vdb_flat_index* ix, const uint64_t* ids, uint64_t f
     vdb::RowStatsParams rp{ix->d_rows, ix->ld, ix->dim, first, first + (uint32_t)n, ix->metric, ix->d_nd,
                            ix->d_alpha, ix->d_beta, ix->d_scalars};
     vdb::launch_row_stats(rp, s);
+    if (ix->d_rows16) vdb::launch_rows_to_bf16(ix->d_rows, ix->d_rows16, ix->ld, first, first + (uint32_t)n, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     ix->n_uploaded = first + (uint32_t)n;
@@ -1479,6 +1501,29 @@ int vdb_flat_set_screen(vdb_flat_index* ix, int mode) {
     if (!ix || mode < 0 || mode > 1) return fail(VDB_ERR_INVALID_ARGUMENT, "mode must be 0 (f32 MFMA tier only) or 1 (bf16 screening tier first)");
     std::lock_guard<std::mutex> g(ix->mu);
     ix->screen = mode;
+    return VDB_OK;
+}
+
+int vdb_flat_set_shadow(vdb_flat_index* ix, int on) {
+    if (!ix || on < 0 || on > 1) return fail(VDB_ERR_INVALID_ARGUMENT, "on must be 0 or 1");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (ix->ctx.pending) return fail(VDB_ERR_INVALID_ARGUMENT, "a search is pending between begin and finish");
+    HIP_TRY(hipSetDevice(ix->device));
+    int rc;
+    if ((rc = flush(ix))) return rc;
+    if (!on) {
+        if (ix->d_rows16) { HIP_TRY(hipStreamSynchronize(ix->stream)); (void)hipFree(ix->d_rows16); }
+        ix->d_rows16 = nullptr; ix->shadow = false;
+        return VDB_OK;
+    }
+    ix->shadow = true;
+    if (!ix->d_rows16 && ix->cap_rows) {
+        HIP_TRY(hipMalloc((void**)&ix->d_rows16, (size_t)ix->cap_rows * ix->ld * 2));
+        HIP_TRY(hipMemsetAsync(ix->d_rows16, 0, (size_t)ix->cap_rows * ix->ld * 2, ix->stream));
+        vdb::launch_rows_to_bf16(ix->d_rows, ix->d_rows16, ix->ld, 0, ix->n_uploaded, ix->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+    }
     return VDB_OK;
 }
 

@@ -255,16 +255,23 @@ class GpuFlatIndex(Index):
         return [out[int(offsets[b]):int(offsets[b + 1])] for b in range(nq)]
 
     def last_stats(self):
-        out = (ctypes.c_uint64 * 14)()
-        self._L.vdb_flat_last_stats_ex(self._h, out, 14)
+        out = (ctypes.c_uint64 * 15)()
+        self._L.vdb_flat_last_stats_ex(self._h, out, 15)
         keys = ["mfma_queries", "exact_queries", "pool_overflows", "rows_scanned", "sample_rows", "kprime",
                 "uncertified", "fused_kernel_ns", "bf16_screen", "f32_tier_queries", "host_enqueued_ns",
-                "host_flags_ns", "host_total_ns", "rethreshold_queries"]
+                "host_flags_ns", "host_total_ns", "rethreshold_queries", "bf16_shadow"]
         return dict(zip(keys, [int(v) for v in out]))
 
     def set_screen(self, mode):
         """1 (default): bf16 screening tier first; 0: f32 MFMA tier only.  Results are identical."""
         rc = self._L.vdb_flat_set_screen(self._h, int(mode))
+        if rc:
+            _raise(rc)
+
+    def set_shadow(self, on=True):
+        """Keep a bf16 shadow copy of the rows (+50 % HBM) for the screening pass to stream instead of the f32 rows.
+        Results are identical; only the bytes the HBM-bound pass reads halve."""
+        rc = self._L.vdb_flat_set_shadow(self._h, int(bool(on)))
         if rc:
             _raise(rc)
 
