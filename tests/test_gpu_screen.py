@@ -86,7 +86,7 @@ def test_screen_tier_vs_oracle_and_f32_tier(vdb, metric, n, d, nq, k, dist):
     a, st, b = both_tiers(ix, q, k)
     assert st["bf16_screen"] == 1 and st["kprime"] == (512 if k > 48 else 256) and st["rows_scanned"] >= n, st
     assert st["pool_overflows"] == 0, st
-    assert st["bf16_shadow"] == (1 if shadow_on() and d > 32 else 0), st
+    assert st["bf16_shadow"] == (1 if shadow_on() else 0), st
     assert same(a, b)
     check_oracle(metric, rows, q, k, a, sorted({0, nq // 2, nq - 1}))
 

@@ -153,7 +153,7 @@ void launch_fused_dma3(const FusedParams& p, uint32_t n_super, hipStream_t s);
 // ---------------------------------------------------------------- bf16 screening tier (kernels_fused_bf16.hip)
 struct FusedBf16Params {
     const float* rows; uint32_t ld; uint32_t n_rows;
-    const uint16_t* rows16;                            // bf16 shadow of `rows` [n_rows][ld] (kernels_fused_a16.hip only; ld >= 64)
+    const uint16_t* rows16;                            // bf16 shadow of `rows` [n_rows][ld] (kernels_fused_a16.hip only)
     const uint16_t* qb;                                // [256][ld] bf16 queries of this pass (zero padded)
     const float* alpha; const float* beta;
     const uint32_t* rowmask;                           // NEVER null: the live mask when there is no filter

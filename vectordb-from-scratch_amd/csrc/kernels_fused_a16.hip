@@ -3,12 +3,17 @@
 // shadow is the RNE rounding of the f32 rows (v_cvt_pk_bf16_f32 at upload) -- exactly what the f32-row kernel computes in
 // registers -- so scores, candidates, certificates and results are bit-identical to that kernel's; only the bytes differ.
 //
-// A stage is 32 K-elements of 256 rows (bf16, 16 KB) and of 256 queries (bf16, 16 KB); FOUR 32 KB images form the
-// LDS ring, so three stages are in flight (the f32-row kernel: three 48 KB images, two in flight).  The wave waits with
-// `s_waitcnt vmcnt(8)` (the 2 x 4 pieces of stages s+1 and s+2 may be outstanding) before the barrier that publishes
-// stage s, then issues stage s+3 into the image stage s-1 just left.  Fragments are read from LDS as bf16 (one
-// ds_read_b128 each, no conversion in the loop).  Everything else -- tile shape, wave layout, constants by LDS-DMA,
-// epilogue, sample mode -- is the f32-row kernel's.
+// A stage is 32 K-elements of 256 rows (bf16, 16 KB) and of 256 queries (bf16, 16 KB).  The rows come from HBM (long
+// latency: many bytes must be in flight), the queries from the L2 (short latency), and a wave's vmcnt counter retires
+// its vector-memory operations IN ORDER -- a wave that fetched both could never have more row stages outstanding than
+// query stages.  So the two kinds are fetched by DIFFERENT waves, each counting only its own kind:
+//   waves 0-3: the rows, into a ring of SIX 16 KB images  -> five row stages (80 KB per CU) in flight;
+//              `s_waitcnt vmcnt(16)` before the barrier that publishes stage s (the 4 x 4 pieces of stages s+1..s+4)
+//   waves 4-7: the queries, into a ring of THREE 16 KB images (two stages in flight, `vmcnt(4)`), and the per-row
+//              constants of the next tile.
+// After the barrier of stage s the row waves issue stage s+5 into the image stage s-1 just left, the query waves
+// stage s+2.  All eight waves compute.  Fragments are read from LDS as bf16 (one ds_read_b128 each, no conversion in
+// the loop).  Tile shape, wave layout, epilogue and sample mode are the f32-row kernel's.
 #include "kernels.h"
 
 #include <type_traits>
@@ -29,7 +34,6 @@ constexpr int A_ROWB = 64;                       // 32 bf16 per row and stage
 constexpr int B_ROWB = 64;                       // 32 bf16 per query and stage
 constexpr int A_BYTES = TR * A_ROWB;             // 16 KB
 constexpr int B_BYTES = TQ * B_ROWB;             // 16 KB
-constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 32 KB
 constexpr int MT = 4, QT = 2;                    // MFMA tiles per wave: 4 x 32 rows, 2 x 32 queries
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -39,16 +43,25 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 template <bool SAMPLE>
 __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
-    // four DISTINCT LDS objects, each access names its image at compile time
-    __shared__ __attribute__((aligned(16))) char sImg0[STAGE_BYTES];
-    __shared__ __attribute__((aligned(16))) char sImg1[STAGE_BYTES];
-    __shared__ __attribute__((aligned(16))) char sImg2[STAGE_BYTES];
-    __shared__ __attribute__((aligned(16))) char sImg3[STAGE_BYTES];
+    // DISTINCT LDS objects, each access names its image at compile time
+    __shared__ __attribute__((aligned(16))) char sA0[A_BYTES];
+    __shared__ __attribute__((aligned(16))) char sA1[A_BYTES];
+    __shared__ __attribute__((aligned(16))) char sA2[A_BYTES];
+    __shared__ __attribute__((aligned(16))) char sA3[A_BYTES];
+    __shared__ __attribute__((aligned(16))) char sA4[A_BYTES];
+    __shared__ __attribute__((aligned(16))) char sA5[A_BYTES];
+    __shared__ __attribute__((aligned(16))) char sB0[B_BYTES];
+    __shared__ __attribute__((aligned(16))) char sB1[B_BYTES];
+    __shared__ __attribute__((aligned(16))) char sB2[B_BYTES];
     // per-row constants of a tile (alpha, beta, the row's eligibility-mask word), double buffered by tile parity;
     // filled by LDS-DMA as well, so that no wave ever holds a pending ordinary load inside the stage loop
     __shared__ __attribute__((aligned(16))) float sAlpha[2 * TR];
     __shared__ __attribute__((aligned(16))) float sBeta[2 * TR];
     __shared__ __attribute__((aligned(16))) uint32_t sMaskW[2 * TR];
+    // sample mode: the device rows of the (single) tile's scattered sample rows, kept here instead of in four 64-bit
+    // address registers per lane (with those the sample instance spilled to scratch, and every scratch reload is a
+    // vmcnt(0) -- a drain of the DMA pipeline -- in the stage loop); each lane reads back only what it wrote
+    __shared__ uint32_t sRow[SAMPLE ? 16 * 64 : 1];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,24 +129,17 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
     const char* __restrict__ rows_b = reinterpret_cast<const char*>(p.rows16);
     const char* __restrict__ bbase = reinterpret_cast<const char*>(p.qb);
 
-    // ---- DMA plan.  A stage image = 16 row pieces + 16 query pieces of 1 KB.  Wave w fills row pieces
-    // 2w, 2w+1 (16 rows x 64 B each: lane L -> row L>>2, 16-byte position L&3) and query pieces 2w, 2w+1
-    // (16 queries x 64 B each, same shape).  Both images are XOR-swizzled so that the fragment reads below are
-    // bank-conflict free: data chunk x of row/query r sits at position x ^ ((r>>2)&3); the filling lane fetches the
-    // permuted source chunk.
+    // ---- DMA plan.  A row image = 16 pieces of 1 KB (16 rows x 64 B each: lane L -> row L>>2, 16-byte position L&3),
+    // a query image likewise.  Row wave w (0-3) fills row pieces 4w..4w+3, query wave w (4-7) query pieces 4(w-4)..+3.
+    // Both images are XOR-swizzled so that the fragment reads below are bank-conflict free: data chunk x of
+    // row/query r sits at position x ^ ((r>>2)&3); the filling lane fetches the permuted source chunk.
+    const bool row_wave = w < 4;                                        // wave-uniform
     const uint32_t a_pr = lane >> 2, a_pp = lane & 3;
-    const uint32_t b_pr = lane >> 2, b_pp = lane & 3;
-    uint32_t a_chunk[2];                                                // source byte offset inside the 64-B stage
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const uint32_t rt = 32 * w + 16 * j + a_pr;                     // row inside the tile
-        a_chunk[j] = (a_pp ^ ((rt >> 2) & 3)) * 16;
-    }
+    const uint32_t a_chunk = (a_pp ^ ((a_pr >> 2) & 3)) * 16;           // same for the wave's four pieces (16-row steps)
     // (the queries are stored by query_prep in exactly this image order, one 16 KB image per K stage: a wave's
     // query piece is 1 KB of CONTIGUOUS global memory -- 8 full 128-byte requests instead of 16 scattered 64-byte ones)
-    const uint32_t ob[2] = {(2 * w) * 1024 + lane * 16, (2 * w + 1) * 1024 + lane * 16};
-    (void)b_pr; (void)b_pp;
-    const char* aptr[2];                                                // row pieces of the tile being fetched
+    const uint32_t ob = (4 * (w & 3)) * 1024 + lane * 16;
+    const char* aptr[4];                                                // row pieces of the tile being fetched
     auto tile_rows_of = [&](uint32_t t, uint32_t rt) -> uint32_t {      // device row of tile-row rt of local tile t
         if (SAMPLE) {
             uint32_t j = (tile_first + t * tile_step) * TR + rt;
@@ -146,17 +152,20 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
     };
     auto set_tile_ptrs = [&](uint32_t t) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const uint32_t row = tile_rows_of(t, 32 * w + 16 * j + a_pr);
-            aptr[j] = rows_b + (size_t)row * ld * 2 + a_chunk[j];
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t row = tile_rows_of(t, 64 * (w & 3) + 16 * j + a_pr);
+            if (SAMPLE) sRow[(4 * (w & 3) + j) * 64 + lane] = row;
+            else aptr[j] = rows_b + (size_t)row * ld * 2 + a_chunk;
         }
     };
-    // The LDS-DMA is issued from inline asm, not through __builtin_amdgcn_global_load_lds: hipcc's waitcnt pass
-    // tracks the builtin as a pending LDS write and, at the loop header of the 3-stage ring, cannot bound how many
-    // vector-memory operations followed the fill of the image about to be read -- it then puts a vmcnt(0) in front
-    // of that stage's first ds_read, which drains the two-stage DMA pipeline.  All ordering between the DMA and the
-    // LDS reads is done by hand here (counted s_waitcnt + s_barrier at the top of each stage); compiler-inserted
-    // vmcnt waits for ordinary loads stay correct because not counting these instructions only makes them wait longer.
+    auto a_piece = [&](int j) -> const char* {
+        if (SAMPLE) return rows_b + (size_t)sRow[(4 * (w & 3) + j) * 64 + lane] * ld * 2 + a_chunk;
+        return aptr[j];
+    };
+    // The LDS-DMA is issued from inline asm, not through __builtin_amdgcn_global_load_lds (see kernels_fused_bf16.hip):
+    // all ordering between the DMA and the LDS reads is done by hand (counted s_waitcnt + s_barrier at the top of
+    // each stage); compiler-inserted vmcnt waits for ordinary loads stay correct because not counting these
+    // instructions only makes them wait longer.
 #define VDB_DMA(GP, IMG, LOFF)                                                                         \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"                     \
                  :: "s"((uint32_t)(uintptr_t)(lds_ptr_t)((IMG) + (LOFF))), "v"((const void*)(GP)) : "memory", "m0")
@@ -164,38 +173,43 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
 #define VDB_DMA_NT(GP, IMG, LOFF)                                                                      \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt"                  \
                  :: "s"((uint32_t)(uintptr_t)(lds_ptr_t)((IMG) + (LOFF))), "v"((const void*)(GP)) : "memory", "m0")
-#define VDB_ISSUE(IMG, KSI)                                                                            \
+#define VDB_ISSUE_A(IMG, KSI)                                                                          \
     {                                                                                                  \
-        const uint32_t la_ = (2 * w) * 1024;                                                           \
-        const uint32_t lb_ = A_BYTES + (2 * w) * 1024;                                                 \
+        const uint32_t la_ = (4 * (w & 3)) * 1024;                                                     \
         const uint32_t ka_ = (KSI) * (KSTAGE * 2);                                                     \
-        const uint32_t kb_ = (KSI) * B_BYTES;                                                          \
         if (!(p.ablate & 2u)) {                                                                        \
-        VDB_DMA_NT(aptr[0] + ka_, IMG, la_);                                                           \
-        VDB_DMA_NT(aptr[1] + ka_, IMG, la_ + 1024);                                                    \
+        const char *g0_ = a_piece(0) + ka_, *g1_ = a_piece(1) + ka_, *g2_ = a_piece(2) + ka_, *g3_ = a_piece(3) + ka_; \
+        VDB_DMA_NT(g0_, IMG, la_);                                                                     \
+        VDB_DMA_NT(g1_, IMG, la_ + 1024);                                                              \
+        VDB_DMA_NT(g2_, IMG, la_ + 2048);                                                              \
+        VDB_DMA_NT(g3_, IMG, la_ + 3072);                                                              \
         }                                                                                              \
+    }
+#define VDB_ISSUE_B(IMG, KSI)                                                                          \
+    {                                                                                                  \
+        const uint32_t lb_ = (4 * (w & 3)) * 1024;                                                     \
+        const uint32_t kb_ = (KSI) * B_BYTES + ob;                                                     \
         if (!(p.ablate & 4u)) {                                                                        \
-        VDB_DMA(bbase + (ob[0] + kb_), IMG, lb_);                                                      \
-        VDB_DMA(bbase + (ob[1] + kb_), IMG, lb_ + 1024);                                               \
+        VDB_DMA(bbase + kb_, IMG, lb_);                                                                \
+        VDB_DMA(bbase + (kb_ + 1024), IMG, lb_ + 1024);                                                \
+        VDB_DMA(bbase + (kb_ + 2048), IMG, lb_ + 2048);                                                \
+        VDB_DMA(bbase + (kb_ + 3072), IMG, lb_ + 3072);                                                \
         }                                                                                              \
     }
 
-    // ---- row constants of a tile, one tile ahead, by LDS-DMA (4 bytes per lane): waves 0-3 fetch alpha and the mask
-    // word of rows 64(w&3)..+63, waves 4-7 fetch beta.  Issued BEFORE the stage's row/query pieces, so the counted
-    // wait at the top of the next stage covers them.
+    // ---- row constants of a tile, one tile ahead, by LDS-DMA (4 bytes per lane): query wave w fetches alpha, beta and
+    // the mask word of rows 64(w-4)..+63.  Issued BEFORE that stage's query pieces, so the counted wait of the query
+    // waves at the top of the next stage covers them, whatever the number of K stages per tile.
 #define VDB_DMA4(GP, LP)                                                                               \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"                        \
                  :: "s"((uint32_t)(uintptr_t)(lds_ptr_t)(LP)), "v"((const void*)(GP)) : "memory", "m0")
-    auto issue_consts = [&](uint32_t t) {
+    auto issue_consts = [&](uint32_t t) {                               // query waves only
         const uint32_t par = t & 1u;
         const uint32_t cr = 64 * (w & 3);                              // first tile-row of this wave's chunk
         const uint32_t row = tile_rows_of(t, cr + lane);
-        if (w < 4) {
-            VDB_DMA4(p.alpha + row, sAlpha + par * TR + cr);
-            VDB_DMA4(p.rowmask + (row >> 5), sMaskW + par * TR + cr);
-        } else {
-            VDB_DMA4(p.beta + row, sBeta + par * TR + cr);
-        }
+        VDB_DMA4(p.alpha + row, sAlpha + par * TR + cr);
+        VDB_DMA4(p.beta + row, sBeta + par * TR + cr);
+        VDB_DMA4(p.rowmask + (row >> 5), sMaskW + par * TR + cr);
     };
 
     f32x16 acc[MT][QT];
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
     // fragment read offsets (bytes inside an image)
     const uint32_t swa = (c >> 2) & 3, swb = (c >> 2) & 3;
     const uint32_t a_row_off = (wr * 128 + c) * A_ROWB;                 // + i*32*A_ROWB
-    const uint32_t b_row_off = A_BYTES + (wq * 64 + c) * B_ROWB;        // + j*32*B_ROWB
+    const uint32_t b_row_off = (wq * 64 + c) * B_ROWB;                  // + j*32*B_ROWB
     uint32_t ra[2], rb[2];                                              // [k-step]
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -217,51 +231,66 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
         rb[t] = ((2 * t + h) ^ swb) * 16;
     }
 
-    // ---- prologue: constants of tile 0 and stages 0, 1 and 2 in flight
+    // ---- prologue: row waves put stages 0..4 in flight, query waves the constants of tile 0 and stages 0, 1
     uint32_t tile = 0, ks = 0;                                          // of the stage being computed
-    uint32_t ftile = 0, fks = 0;                                        // of the next stage to fetch
-    set_tile_ptrs(0);
-    issue_consts(0);
-    VDB_ISSUE(sImg0, 0u)
-    fks = 1;
-    if (fks == KS) { fks = 0; ftile = 1; if (ftile < ntiles) set_tile_ptrs(ftile); }
-    if (total > 1) {
-        VDB_ISSUE(sImg1, fks)
-        ++fks;
-        if (fks == KS) { fks = 0; ++ftile; if (ftile < ntiles) set_tile_ptrs(ftile); }
+    uint32_t ftile = 0, fks = 0;                                        // of the next row stage to fetch
+    uint32_t bks = 0;                                                   // K stage of the next query stage to fetch
+#define VDB_ADV_A                                                                                      \
+    {                                                                                                  \
+        ++fks;                                                                                         \
+        if (fks == KS) { fks = 0; ++ftile; if (ftile < ntiles) set_tile_ptrs(ftile); }                 \
     }
-    if (total > 2) {
-        VDB_ISSUE(sImg2, fks)
-        ++fks;
-        if (fks == KS) { fks = 0; ++ftile; if (ftile < ntiles) set_tile_ptrs(ftile); }
+#define VDB_ADV_B { ++bks; if (bks == KS) bks = 0; }
+    if (row_wave) {
+        set_tile_ptrs(0);
+        VDB_ISSUE_A(sA0, fks) VDB_ADV_A
+        if (total > 1) { VDB_ISSUE_A(sA1, fks) VDB_ADV_A }
+        if (total > 2) { VDB_ISSUE_A(sA2, fks) VDB_ADV_A }
+        if (total > 3) { VDB_ISSUE_A(sA3, fks) VDB_ADV_A }
+        if (total > 4) { VDB_ISSUE_A(sA4, fks) VDB_ADV_A }
+    } else {
+        issue_consts(0);
+        VDB_ISSUE_B(sB0, bks) VDB_ADV_B
+        if (total > 1) { VDB_ISSUE_B(sB1, bks) VDB_ADV_B }
     }
 
-    // STEADY: the caller guarantees st + 3 < total, so the wait and the DMA issue are unconditional (see the f32-row
+    // STEADY: the caller guarantees st + 5 < total, so the waits and the DMA issue are unconditional (see the f32-row
     // kernel for why that matters to hipcc's waitcnt pass).
-    auto run_stage = [&](uint32_t st, auto buf_tag, auto steady_tag) {
-        constexpr int BUF = decltype(buf_tag)::value;
+    auto run_stage = [&](uint32_t st, auto abuf_tag, auto bbuf_tag, auto steady_tag) {
+        constexpr int AB = decltype(abuf_tag)::value;                   // st mod 6
+        constexpr int BB = decltype(bbuf_tag)::value;                   // st mod 3
         constexpr bool STEADY = decltype(steady_tag)::value;
-        const char* img = BUF == 0 ? sImg0 : BUF == 1 ? sImg1 : BUF == 2 ? sImg2 : sImg3;
-        char* img_fill = BUF == 0 ? sImg3 : BUF == 1 ? sImg0 : BUF == 2 ? sImg1 : sImg2;   // stage st+3 goes where stage st-1 was
-        // publish stage st: this wave's pieces have landed once at most the 2 x 4 pieces of stages st+1, st+2 are outstanding
-        // (a bare s_barrier: __syncthreads() carries a fence that hipcc lowers to vmcnt(0), which would drain the
-        // DMA pipeline at every stage; LDS writes are waited for explicitly, and the asm memory clobbers keep
-        // the compiler from moving LDS accesses across)
-        if (STEADY || st + 2 < total) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else if (st + 1 < total) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const char* imgA = AB == 0 ? sA0 : AB == 1 ? sA1 : AB == 2 ? sA2 : AB == 3 ? sA3 : AB == 4 ? sA4 : sA5;
+        char* fillA = AB == 0 ? sA5 : AB == 1 ? sA0 : AB == 2 ? sA1 : AB == 3 ? sA2 : AB == 4 ? sA3 : sA4;   // stage st+5 goes where stage st-1 was
+        const char* imgB = BB == 0 ? sB0 : BB == 1 ? sB1 : sB2;
+        char* fillB = BB == 0 ? sB2 : BB == 1 ? sB0 : sB1;              // stage st+2 goes where stage st-1 was
+        // publish stage st: a row wave's pieces of it have landed once at most the 4 x 4 pieces of stages st+1..st+4
+        // are outstanding, a query wave's once at most the 4 pieces of stage st+1 are (a bare s_barrier:
+        // __syncthreads() carries a fence that hipcc lowers to vmcnt(0), which would drain the DMA pipeline at every
+        // stage; LDS writes are waited for explicitly, and the asm memory clobbers keep the compiler from moving LDS
+        // accesses across)
+        if (row_wave) {
+            if (STEADY || st + 4 < total) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+            else if (st + 3 < total) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+            else if (st + 2 < total) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (st + 1 < total) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        } else {
+            if (STEADY || st + 1 < total) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // constants of the NEXT tile into the other parity (every wave is past the epilogue that read it)
-        if (ks == 0 && tile + 1 < ntiles) issue_consts(tile + 1);
-        if (STEADY || st + 3 < total) {
-            VDB_ISSUE(img_fill, fks)
-            ++fks;
-            if (fks == KS) { fks = 0; ++ftile; if (ftile < ntiles) set_tile_ptrs(ftile); }
+        if (row_wave) {
+            if (STEADY || st + 5 < total) { VDB_ISSUE_A(fillA, fks) VDB_ADV_A }
+        } else {
+            // constants of the NEXT tile into the other parity (every wave is past the epilogue that read it)
+            if (ks == 0 && tile + 1 < ntiles) issue_consts(tile + 1);
+            if (STEADY || st + 2 < total) { VDB_ISSUE_B(fillB, bks) VDB_ADV_B }
         }
         // ---- 2 k-steps of 16: fragments -> bf16 -> 8 MFMAs each
-        const char* ap = img + a_row_off;
-        const char* bp = img + b_row_off;
+        const char* ap = imgA + a_row_off;
+        const char* bp = imgB + b_row_off;
         if (!(p.ablate & 1u))
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -285,8 +314,8 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
 
         if (ks == KS - 1 && !(p.ablate & 8u)) {
             const uint32_t par = tile & 1u;
-            // (the constants of this tile were issued at least two K stages ago -- the launcher requires ld >= 64 -- and
-            // before the pieces of a stage whose top-of-stage wait has already been passed, so they have landed)
+            // (the constants of this tile were issued by the query waves before the query pieces of a stage whose
+            // top-of-stage wait + barrier every wave has passed, so they have landed)
             uint32_t tr0;                                               // device row of tile-row 0 (filter mode)
             uint32_t sj0 = 0;                                           // sample index of tile-row 0 (sample mode)
             if (SAMPLE) { sj0 = (tile_first + tile * tile_step) * TR; tr0 = 0; }
@@ -381,24 +410,32 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
         if (ks == KS) { ks = 0; ++tile; }
     };
 
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-    using B2 = std::integral_constant<int, 2>;
-    using B3 = std::integral_constant<int, 3>;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>;
+    using I5 = std::integral_constant<int, 5>;
     uint32_t st = 0;
-    for (; st + 6 < total; st += 4) {                                   // stage index mod 4 == image index
-        run_stage(st, B0{}, std::true_type{});
-        run_stage(st + 1, B1{}, std::true_type{});
-        run_stage(st + 2, B2{}, std::true_type{});
-        run_stage(st + 3, B3{}, std::true_type{});
+    for (; st + 10 < total; st += 6) {                                  // stage index mod 6 / mod 3 == image index
+        run_stage(st, I0{}, I0{}, std::true_type{});
+        run_stage(st + 1, I1{}, I1{}, std::true_type{});
+        run_stage(st + 2, I2{}, I2{}, std::true_type{});
+        run_stage(st + 3, I3{}, I0{}, std::true_type{});
+        run_stage(st + 4, I4{}, I1{}, std::true_type{});
+        run_stage(st + 5, I5{}, I2{}, std::true_type{});
     }
-    // the last one to six stages: conditional issue
-    if (st < total) { run_stage(st, B0{}, std::false_type{}); ++st; }
-    if (st < total) { run_stage(st, B1{}, std::false_type{}); ++st; }
-    if (st < total) { run_stage(st, B2{}, std::false_type{}); ++st; }
-    if (st < total) { run_stage(st, B3{}, std::false_type{}); ++st; }
-    if (st < total) { run_stage(st, B0{}, std::false_type{}); ++st; }
-    if (st < total) { run_stage(st, B1{}, std::false_type{}); ++st; }
+    // the last one to ten stages: conditional issue
+    if (st < total) { run_stage(st, I0{}, I0{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I1{}, I1{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I2{}, I2{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I3{}, I0{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I4{}, I1{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I5{}, I2{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I0{}, I0{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I1{}, I1{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I2{}, I2{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I3{}, I0{}, std::false_type{}); ++st; }
     if (!SAMPLE) {
         p.pool_cnt[sub_a] = pcnt_a;
         p.pool_cnt[sub_b] = pcnt_b;
@@ -406,7 +443,10 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
 #undef VDB_DMA
 #undef VDB_DMA_NT
 #undef VDB_DMA4
-#undef VDB_ISSUE
+#undef VDB_ISSUE_A
+#undef VDB_ISSUE_B
+#undef VDB_ADV_A
+#undef VDB_ADV_B
 }
 
 // same tile shape, sub-pool and sample-group layout as the f32-row kernel (fused_bf16_tile_rows & co.)
