@@ -209,8 +209,10 @@ int vdb_flat_set_screen(vdb_flat_index *h, int mode);
  * pass then streams the shadow -- half the bytes of the HBM-bound pass -- and computes exactly the scores it computes
  * from the f32 rows (the same RNE conversion, done once at upload instead of in the kernel).  The exact re-rank, the
  * certificates and every fallback tier keep reading the f32 rows.  Existing rows are converted by the call, later adds
- * maintain the shadow; on = 0 frees it.  VDB_SHADOW=1 turns it on for every handle created afterwards.
- * vdb_flat_last_stats_ex()[14] = 1 when the last search screened from the shadow. */
+ * maintain the shadow; on = 0 frees it.  VDB_SHADOW=1 turns it on for every handle created afterwards.  The
+ * shadow is read when the dimension, padded to a multiple of 32, is a multiple of 64 (768, 1536, 128, 100 ...); other
+ * dimensions are screened from the f32 rows.  vdb_flat_last_stats_ex()[14] = 1 when the last search screened from the
+ * shadow. */
 int vdb_flat_set_shadow(vdb_flat_index *h, int on);
 
 /* Thread-local message of the last failing call on this thread, plus the

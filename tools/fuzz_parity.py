@@ -107,7 +107,7 @@ def main():
             st2 = ix.last_stats()
             keys = ["bf16_screen", "rethreshold_queries", "f32_tier_queries", "exact_queries", "pool_overflows", "uncertified"]
             shadow_ok = all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(a1, a2)) and all(st[x] == st2[x] for x in keys)
-            shadow_ok &= st2["bf16_shadow"] == 0 and st["bf16_shadow"] == (1 if st["bf16_screen"] else 0)
+            shadow_ok &= st2["bf16_shadow"] == 0 and st["bf16_shadow"] == (1 if st["bf16_screen"] and ((d + 31) // 32) % 2 == 0 else 0)
         ix.set_screen(0)
         a0 = ix.search_batch_arrays(queries, k, **kw)
         ok = shadow_ok and all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(a1, a0))

@@ -153,7 +153,7 @@ void launch_fused_dma3(const FusedParams& p, uint32_t n_super, hipStream_t s);
 // ---------------------------------------------------------------- bf16 screening tier (kernels_fused_bf16.hip)
 struct FusedBf16Params {
     const float* rows; uint32_t ld; uint32_t n_rows;
-    const uint16_t* rows16;                            // bf16 shadow of `rows` [n_rows][ld] (kernels_fused_a16.hip only)
+    const uint16_t* rows16;                            // bf16 shadow of `rows` [n_rows][ld] (kernels_fused_a16.hip; used when ld % 64 == 0)
     const uint16_t* qb;                                // [256][ld] bf16 queries of this pass (zero padded)
     const float* alpha; const float* beta;
     const uint32_t* rowmask;                           // NEVER null: the live mask when there is no filter
@@ -169,8 +169,7 @@ struct FusedBf16Params {
 };
 void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s);
 void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s);
-void launch_fused_a16(const FusedBf16Params& p, hipStream_t s);      // the same kernels reading p.rows16
-void launch_sample_a16(const FusedBf16Params& p, hipStream_t s);
+void launch_fused_a16(const FusedBf16Params& p, hipStream_t s);      // the filter pass reading p.rows16 (ld % 64 == 0)
 uint32_t fused_bf16_tile_rows();
 uint32_t fused_bf16_subpools_per_query(uint32_t n_wg);
 uint32_t fused_bf16_sample_groups(uint32_t n_sample);

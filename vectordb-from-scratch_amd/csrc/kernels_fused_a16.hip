@@ -3,17 +3,21 @@
 // shadow is the RNE rounding of the f32 rows (v_cvt_pk_bf16_f32 at upload) -- exactly what the f32-row kernel computes in
 // registers -- so scores, candidates, certificates and results are bit-identical to that kernel's; only the bytes differ.
 //
-// A stage is 32 K-elements of 256 rows (bf16, 16 KB) and of 256 queries (bf16, 16 KB).  The rows come from HBM (long
-// latency: many bytes must be in flight), the queries from the L2 (short latency), and a wave's vmcnt counter retires
-// its vector-memory operations IN ORDER -- a wave that fetched both could never have more row stages outstanding than
-// query stages.  So the two kinds are fetched by DIFFERENT waves, each counting only its own kind:
-//   waves 0-3: the rows, into a ring of SIX 16 KB images  -> five row stages (80 KB per CU) in flight;
-//              `s_waitcnt vmcnt(16)` before the barrier that publishes stage s (the 4 x 4 pieces of stages s+1..s+4)
-//   waves 4-7: the queries, into a ring of THREE 16 KB images (two stages in flight, `vmcnt(4)`), and the per-row
-//              constants of the next tile.
-// After the barrier of stage s the row waves issue stage s+5 into the image stage s-1 just left, the query waves
-// stage s+2.  All eight waves compute.  Fragments are read from LDS as bf16 (one ds_read_b128 each, no conversion in
-// the loop).  Tile shape, wave layout, epilogue and sample mode are the f32-row kernel's.
+// A stage is 32 K-elements of 256 rows and of 256 queries (bf16, 16 KB each).  Two things shape the fetch:
+//  * The rows come from HBM, and the memory system retires REQUESTS, not bytes: with 64-byte row segments (one K stage
+//    of a bf16 row) the pass ran at the same ~55 G requests/s as the f32-row kernel and therefore at half its bytes/s.
+//    So the rows are fetched TWO K stages at a time -- 128 contiguous bytes per row, one full cache line per request --
+//    into 32 KB row images that each serve two stages.
+//  * The queries come from the L2, and a wave's vmcnt counter retires its vector-memory operations IN ORDER: a wave that
+//    fetched both kinds could never have more row stages outstanding than query stages.  So the two kinds are fetched
+//    by DIFFERENT waves, each counting only its own kind:
+//      waves 0-3: the rows, a ring of THREE 32 KB images (two double stages = 64 KB per CU in flight); 8 pieces per
+//                 wave at every even stage, `s_waitcnt vmcnt(8)` before the barrier that publishes an even stage;
+//      waves 4-7: the queries, a ring of THREE 16 KB images (two stages in flight, `vmcnt(4)`), and the per-row
+//                 constants of the next tile.
+// All eight waves compute.  Fragments are read from LDS as bf16 (one ds_read_b128 each, no conversion in the loop).
+// Tile shape, wave layout, epilogue and sample mode are the f32-row kernel's.  Requires an even number of K stages
+// per row (padded dimension a multiple of 64); the host uses the f32-row kernel otherwise.
 #include "kernels.h"
 
 #include <type_traits>
@@ -30,9 +34,9 @@ namespace {
 constexpr int NW = 8, NT = NW * 64;
 constexpr int TR = 256;                          // rows per tile
 constexpr int TQ = 256;                          // queries per tile
-constexpr int A_ROWB = 64;                       // 32 bf16 per row and stage
+constexpr int A_ROWB = 128;                      // 64 bf16 per row: TWO K stages per row image
 constexpr int B_ROWB = 64;                       // 32 bf16 per query and stage
-constexpr int A_BYTES = TR * A_ROWB;             // 16 KB
+constexpr int A_BYTES = TR * A_ROWB;             // 32 KB
 constexpr int B_BYTES = TQ * B_ROWB;             // 16 KB
 constexpr int MT = 4, QT = 2;                    // MFMA tiles per wave: 4 x 32 rows, 2 x 32 queries
 
@@ -47,9 +51,6 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
     __shared__ __attribute__((aligned(16))) char sA0[A_BYTES];
     __shared__ __attribute__((aligned(16))) char sA1[A_BYTES];
     __shared__ __attribute__((aligned(16))) char sA2[A_BYTES];
-    __shared__ __attribute__((aligned(16))) char sA3[A_BYTES];
-    __shared__ __attribute__((aligned(16))) char sA4[A_BYTES];
-    __shared__ __attribute__((aligned(16))) char sA5[A_BYTES];
     __shared__ __attribute__((aligned(16))) char sB0[B_BYTES];
     __shared__ __attribute__((aligned(16))) char sB1[B_BYTES];
     __shared__ __attribute__((aligned(16))) char sB2[B_BYTES];
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
     // sample mode: the device rows of the (single) tile's scattered sample rows, kept here instead of in four 64-bit
     // address registers per lane (with those the sample instance spilled to scratch, and every scratch reload is a
     // vmcnt(0) -- a drain of the DMA pipeline -- in the stage loop); each lane reads back only what it wrote
-    __shared__ uint32_t sRow[SAMPLE ? 16 * 64 : 1];
+    __shared__ uint32_t sRow[SAMPLE ? 32 * 64 : 1];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,17 +130,23 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
     const char* __restrict__ rows_b = reinterpret_cast<const char*>(p.rows16);
     const char* __restrict__ bbase = reinterpret_cast<const char*>(p.qb);
 
-    // ---- DMA plan.  A row image = 16 pieces of 1 KB (16 rows x 64 B each: lane L -> row L>>2, 16-byte position L&3),
-    // a query image likewise.  Row wave w (0-3) fills row pieces 4w..4w+3, query wave w (4-7) query pieces 4(w-4)..+3.
-    // Both images are XOR-swizzled so that the fragment reads below are bank-conflict free: data chunk x of
-    // row/query r sits at position x ^ ((r>>2)&3); the filling lane fetches the permuted source chunk.
+    // ---- DMA plan.  A row image = 32 pieces of 1 KB (8 rows x 128 B each: lane L -> row L>>3, 16-byte position L&7),
+    // a query image = 16 pieces (16 queries x 64 B: lane L -> query L>>2, position L&3).  Row wave w (0-3) fills row
+    // pieces 8w..8w+7, query wave w (4-7) query pieces 4(w-4)..+3.  Both images are XOR-swizzled so that the fragment
+    // reads below are bank-conflict free: data chunk x of row r sits at position x ^ ((r>>1)&7), data chunk x of query r
+    // at position x ^ ((r>>2)&3); the filling lane fetches the permuted source chunk.
     const bool row_wave = w < 4;                                        // wave-uniform
-    const uint32_t a_pr = lane >> 2, a_pp = lane & 3;
-    const uint32_t a_chunk = (a_pp ^ ((a_pr >> 2) & 3)) * 16;           // same for the wave's four pieces (16-row steps)
+    const uint32_t a_pr = lane >> 3, a_pp = lane & 7;
+    // tile-row of piece j: rt = 64w + 8j + a_pr, so (rt>>1)&7 = (4(j&1) + (a_pr>>1)) & 7: one source chunk for even j, one for odd j
+    const uint32_t a_chunk0 = (a_pp ^ ((a_pr >> 1) & 7)) * 16, a_chunk1 = (a_pp ^ ((4 + (a_pr >> 1)) & 7)) * 16;
     // (the queries are stored by query_prep in exactly this image order, one 16 KB image per K stage: a wave's
     // query piece is 1 KB of CONTIGUOUS global memory -- 8 full 128-byte requests instead of 16 scattered 64-byte ones)
     const uint32_t ob = (4 * (w & 3)) * 1024 + lane * 16;
-    const char* aptr[4];                                                // row pieces of the tile being fetched
+    // filter mode: the tile's rows are contiguous (the store is allocated and zero-filled in multiples of 256 rows, so
+    // tile rows past the last row are readable; the eligibility ballots of the epilogue keep them out): pieces j, j+2
+    // are 16 rows apart -> two base pointers (even j, odd j) and a uniform stride
+    const char* aptr0 = nullptr; const char* aptr1 = nullptr;
+    const size_t a_pair_stride = (size_t)16 * ld * 2;
     auto tile_rows_of = [&](uint32_t t, uint32_t rt) -> uint32_t {      // device row of tile-row rt of local tile t
         if (SAMPLE) {
             uint32_t j = (tile_first + t * tile_step) * TR + rt;
@@ -151,16 +158,18 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
         }
     };
     auto set_tile_ptrs = [&](uint32_t t) {
+        if (SAMPLE) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t row = tile_rows_of(t, 64 * (w & 3) + 16 * j + a_pr);
-            if (SAMPLE) sRow[(4 * (w & 3) + j) * 64 + lane] = row;
-            else aptr[j] = rows_b + (size_t)row * ld * 2 + a_chunk;
+            for (int j = 0; j < 8; ++j) sRow[(8 * (w & 3) + j) * 64 + lane] = tile_rows_of(t, 64 * (w & 3) + 8 * j + a_pr);
+        } else {
+            const uint32_t row = r0 + t * TR + 64 * (w & 3) + a_pr;    // unclamped, see above
+            aptr0 = rows_b + (size_t)row * ld * 2 + a_chunk0;
+            aptr1 = rows_b + (size_t)(row + 8) * ld * 2 + a_chunk1;
         }
     };
     auto a_piece = [&](int j) -> const char* {
-        if (SAMPLE) return rows_b + (size_t)sRow[(4 * (w & 3) + j) * 64 + lane] * ld * 2 + a_chunk;
-        return aptr[j];
+        if (SAMPLE) return rows_b + (size_t)sRow[(8 * (w & 3) + j) * 64 + lane] * ld * 2 + ((j & 1) ? a_chunk1 : a_chunk0);
+        return ((j & 1) ? aptr1 : aptr0) + (size_t)(j >> 1) * a_pair_stride;
     };
     // The LDS-DMA is issued from inline asm, not through __builtin_amdgcn_global_load_lds (see kernels_fused_bf16.hip):
     // all ordering between the DMA and the LDS reads is done by hand (counted s_waitcnt + s_barrier at the top of
@@ -173,16 +182,15 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
 #define VDB_DMA_NT(GP, IMG, LOFF)                                                                      \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt"                  \
                  :: "s"((uint32_t)(uintptr_t)(lds_ptr_t)((IMG) + (LOFF))), "v"((const void*)(GP)) : "memory", "m0")
-#define VDB_ISSUE_A(IMG, KSI)                                                                          \
+#define VDB_ISSUE_A(IMG, SSI)                                                                          \
     {                                                                                                  \
-        const uint32_t la_ = (4 * (w & 3)) * 1024;                                                     \
-        const uint32_t ka_ = (KSI) * (KSTAGE * 2);                                                     \
+        const uint32_t la_ = (8 * (w & 3)) * 1024;                                                     \
+        const uint32_t ka_ = (SSI) * A_ROWB;                                                           \
         if (!(p.ablate & 2u)) {                                                                        \
-        const char *g0_ = a_piece(0) + ka_, *g1_ = a_piece(1) + ka_, *g2_ = a_piece(2) + ka_, *g3_ = a_piece(3) + ka_; \
-        VDB_DMA_NT(g0_, IMG, la_);                                                                     \
-        VDB_DMA_NT(g1_, IMG, la_ + 1024);                                                              \
-        VDB_DMA_NT(g2_, IMG, la_ + 2048);                                                              \
-        VDB_DMA_NT(g3_, IMG, la_ + 3072);                                                              \
+        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                             \
+            const char* g_ = a_piece(j_) + ka_;                                                        \
+            VDB_DMA_NT(g_, IMG, la_ + j_ * 1024);                                                      \
+        }                                                                                              \
         }                                                                                              \
     }
 #define VDB_ISSUE_B(IMG, KSI)                                                                          \
@@ -221,59 +229,58 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // fragment read offsets (bytes inside an image)
-    const uint32_t swa = (c >> 2) & 3, swb = (c >> 2) & 3;
+    const uint32_t swa = (c >> 1) & 7, swb = (c >> 2) & 3;
     const uint32_t a_row_off = (wr * 128 + c) * A_ROWB;                 // + i*32*A_ROWB
     const uint32_t b_row_off = (wq * 64 + c) * B_ROWB;                  // + j*32*B_ROWB
-    uint32_t ra[2], rb[2];                                              // [k-step]
+    uint32_t ra[2][2], rb[2];                                           // [stage half of the row image][k-step], [k-step]
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        ra[t] = ((2 * t + h) ^ swa) * 16;
+        ra[0][t] = ((2 * t + h) ^ swa) * 16;
+        ra[1][t] = ((4 + 2 * t + h) ^ swa) * 16;
         rb[t] = ((2 * t + h) ^ swb) * 16;
     }
 
-    // ---- prologue: row waves put stages 0..4 in flight, query waves the constants of tile 0 and stages 0, 1
+    // ---- prologue: row waves put double stages 0 and 1 in flight, query waves the constants of tile 0 and stages 0, 1
     uint32_t tile = 0, ks = 0;                                          // of the stage being computed
-    uint32_t ftile = 0, fks = 0;                                        // of the next row stage to fetch
+    uint32_t ftile = 0, fss = 0;                                        // of the next row double stage to fetch
     uint32_t bks = 0;                                                   // K stage of the next query stage to fetch
+    const uint32_t SS = KS >> 1;                                        // double stages per tile (KS is even)
 #define VDB_ADV_A                                                                                      \
     {                                                                                                  \
-        ++fks;                                                                                         \
-        if (fks == KS) { fks = 0; ++ftile; if (ftile < ntiles) set_tile_ptrs(ftile); }                 \
+        ++fss;                                                                                         \
+        if (fss == SS) { fss = 0; ++ftile; if (ftile < ntiles) set_tile_ptrs(ftile); }                 \
     }
 #define VDB_ADV_B { ++bks; if (bks == KS) bks = 0; }
     if (row_wave) {
         set_tile_ptrs(0);
-        VDB_ISSUE_A(sA0, fks) VDB_ADV_A
-        if (total > 1) { VDB_ISSUE_A(sA1, fks) VDB_ADV_A }
-        if (total > 2) { VDB_ISSUE_A(sA2, fks) VDB_ADV_A }
-        if (total > 3) { VDB_ISSUE_A(sA3, fks) VDB_ADV_A }
-        if (total > 4) { VDB_ISSUE_A(sA4, fks) VDB_ADV_A }
+        VDB_ISSUE_A(sA0, fss) VDB_ADV_A
+        if (total > 2) { VDB_ISSUE_A(sA1, fss) VDB_ADV_A }
     } else {
         issue_consts(0);
         VDB_ISSUE_B(sB0, bks) VDB_ADV_B
-        if (total > 1) { VDB_ISSUE_B(sB1, bks) VDB_ADV_B }
+        VDB_ISSUE_B(sB1, bks) VDB_ADV_B                                 // total >= 2
     }
 
-    // STEADY: the caller guarantees st + 5 < total, so the waits and the DMA issue are unconditional (see the f32-row
-    // kernel for why that matters to hipcc's waitcnt pass).
-    auto run_stage = [&](uint32_t st, auto abuf_tag, auto bbuf_tag, auto steady_tag) {
-        constexpr int AB = decltype(abuf_tag)::value;                   // st mod 6
-        constexpr int BB = decltype(bbuf_tag)::value;                   // st mod 3
+    // STEADY: the caller guarantees st + 4 < total at even stages and st + 2 < total at all, so the waits and the DMA
+    // issue are unconditional (see the f32-row kernel for why that matters to hipcc's waitcnt pass).
+    auto run_stage = [&](uint32_t st, auto pos_tag, auto steady_tag) {
+        constexpr int K6 = decltype(pos_tag)::value;                    // st mod 6
+        constexpr int AB = K6 >> 1;                                     // row image (two stages each)
+        constexpr int U = K6 & 1;                                       // which half of the row image
+        constexpr int BB = K6 % 3;                                      // query image
         constexpr bool STEADY = decltype(steady_tag)::value;
-        const char* imgA = AB == 0 ? sA0 : AB == 1 ? sA1 : AB == 2 ? sA2 : AB == 3 ? sA3 : AB == 4 ? sA4 : sA5;
-        char* fillA = AB == 0 ? sA5 : AB == 1 ? sA0 : AB == 2 ? sA1 : AB == 3 ? sA2 : AB == 4 ? sA3 : sA4;   // stage st+5 goes where stage st-1 was
+        const char* imgA = AB == 0 ? sA0 : AB == 1 ? sA1 : sA2;
+        char* fillA = AB == 0 ? sA2 : AB == 1 ? sA0 : sA1;              // double stage S+2 goes where double stage S-1 was
         const char* imgB = BB == 0 ? sB0 : BB == 1 ? sB1 : sB2;
         char* fillB = BB == 0 ? sB2 : BB == 1 ? sB0 : sB1;              // stage st+2 goes where stage st-1 was
-        // publish stage st: a row wave's pieces of it have landed once at most the 4 x 4 pieces of stages st+1..st+4
-        // are outstanding, a query wave's once at most the 4 pieces of stage st+1 are (a bare s_barrier:
-        // __syncthreads() carries a fence that hipcc lowers to vmcnt(0), which would drain the DMA pipeline at every
-        // stage; LDS writes are waited for explicitly, and the asm memory clobbers keep the compiler from moving LDS
-        // accesses across)
+        // publish stage st: a row wave's pieces of an even stage's image have landed once at most the 8 pieces of the
+        // next double stage are outstanding (an odd stage reads the image its even stage published), a query wave's
+        // once at most the 4 pieces of stage st+1 are (a bare s_barrier: __syncthreads() carries a fence that hipcc
+        // lowers to vmcnt(0), which would drain the DMA pipeline at every stage; LDS writes are waited for
+        // explicitly, and the asm memory clobbers keep the compiler from moving LDS accesses across)
         if (row_wave) {
-            if (STEADY || st + 4 < total) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-            else if (st + 3 < total) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-            else if (st + 2 < total) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            else if (st + 1 < total) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            if (U == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (STEADY || st + 2 < total) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         } else {
             if (STEADY || st + 1 < total) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (row_wave) {
-            if (STEADY || st + 5 < total) { VDB_ISSUE_A(fillA, fks) VDB_ADV_A }
+            if (U == 0 && (STEADY || st + 4 < total)) { VDB_ISSUE_A(fillA, fss) VDB_ADV_A }
         } else {
             // constants of the NEXT tile into the other parity (every wave is past the epilogue that read it)
             if (ks == 0 && tile + 1 < ntiles) issue_consts(tile + 1);
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
             bf16x8 fa[MT], fb[QT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const u32x4 raw = *reinterpret_cast<const u32x4*>(ap + i * 32 * A_ROWB + ra[t]);
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(ap + i * 32 * A_ROWB + ra[U][t]);
                 fa[i] = __builtin_bit_cast(bf16x8, raw);
             }
 #pragma unroll
@@ -417,25 +424,23 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
     using I4 = std::integral_constant<int, 4>;
     using I5 = std::integral_constant<int, 5>;
     uint32_t st = 0;
-    for (; st + 10 < total; st += 6) {                                  // stage index mod 6 / mod 3 == image index
-        run_stage(st, I0{}, I0{}, std::true_type{});
-        run_stage(st + 1, I1{}, I1{}, std::true_type{});
-        run_stage(st + 2, I2{}, I2{}, std::true_type{});
-        run_stage(st + 3, I3{}, I0{}, std::true_type{});
-        run_stage(st + 4, I4{}, I1{}, std::true_type{});
-        run_stage(st + 5, I5{}, I2{}, std::true_type{});
+    for (; st + 8 < total; st += 6) {                                   // (stage index mod 6) >> 1 and mod 3 == image indices
+        run_stage(st, I0{}, std::true_type{});
+        run_stage(st + 1, I1{}, std::true_type{});
+        run_stage(st + 2, I2{}, std::true_type{});
+        run_stage(st + 3, I3{}, std::true_type{});
+        run_stage(st + 4, I4{}, std::true_type{});
+        run_stage(st + 5, I5{}, std::true_type{});
     }
-    // the last one to ten stages: conditional issue
-    if (st < total) { run_stage(st, I0{}, I0{}, std::false_type{}); ++st; }
-    if (st < total) { run_stage(st, I1{}, I1{}, std::false_type{}); ++st; }
-    if (st < total) { run_stage(st, I2{}, I2{}, std::false_type{}); ++st; }
-    if (st < total) { run_stage(st, I3{}, I0{}, std::false_type{}); ++st; }
-    if (st < total) { run_stage(st, I4{}, I1{}, std::false_type{}); ++st; }
-    if (st < total) { run_stage(st, I5{}, I2{}, std::false_type{}); ++st; }
-    if (st < total) { run_stage(st, I0{}, I0{}, std::false_type{}); ++st; }
-    if (st < total) { run_stage(st, I1{}, I1{}, std::false_type{}); ++st; }
-    if (st < total) { run_stage(st, I2{}, I2{}, std::false_type{}); ++st; }
-    if (st < total) { run_stage(st, I3{}, I0{}, std::false_type{}); ++st; }
+    // the last two to eight stages (total is even): conditional issue
+    if (st < total) { run_stage(st, I0{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I1{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I2{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I3{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I4{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I5{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I0{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I1{}, std::false_type{}); ++st; }
     if (!SAMPLE) {
         p.pool_cnt[sub_a] = pcnt_a;
         p.pool_cnt[sub_b] = pcnt_b;
@@ -453,10 +458,8 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
 void launch_fused_a16(const FusedBf16Params& p, hipStream_t s) {
     hipLaunchKernelGGL(fused_a16_kernel<false>, dim3(p.n_wg), dim3(NT), 0, s, p);
 }
-void launch_sample_a16(const FusedBf16Params& p, hipStream_t s) {
-    const uint32_t stiles = (p.n_sample + TR - 1) / TR;
-    if (!stiles) return;
-    hipLaunchKernelGGL(fused_a16_kernel<true>, dim3(stiles), dim3(NT), 0, s, p);
-}
+// (the sample pass -- 65536 rows, a tenth of a millisecond's worth of the f32-row kernel -- keeps reading the f32 rows:
+// the <true> instance of this kernel needs more than the 256 registers a wave has here and would spill into the stage
+// loop; its thresholds are the same either way, so the candidates are identical too)
 
 }  // namespace vdb

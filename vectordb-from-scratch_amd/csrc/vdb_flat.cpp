@@ -597,15 +597,14 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         vdb::FusedBf16Params fp{};
         fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w_qb.p + (size_t)q0 * ld;
         fp.rows16 = ix->d_rows16;
-        const bool a16 = ix->d_rows16 != nullptr;
+        const bool a16 = ix->d_rows16 && ld % 64 == 0;         // the shadow kernel fetches two K stages (one 128-byte line) per row request
         ix->stats[14] = a16;
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
         fp.thr = ix->w_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
         fp.ablate = getenv("VDB_BF16_ABLATE") ? (uint32_t)atoi(getenv("VDB_BF16_ABLATE")) : 0u;
         fp.n_sample = S; fp.sample_shift = pl.shift;
         fp.sample_block = getenv("VDB_SAMPLE_BLOCK") ? (n / (S / 256u)) : 0u; fp.minkeys = ix->w_dense.p; fp.minkey_stride = M;
-        if (a16) vdb::launch_sample_a16(fp, s);
-        else vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);
+        vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);    // (the sample always reads the f32 rows)
 
         vdb::SelectParams sp{};
         sp.keys = ix->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = KT;
@@ -695,7 +694,7 @@ int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo
         fp.rows16 = ix->d_rows16;
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
         fp.thr = ix->w2_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
-        if (ix->d_rows16) vdb::launch_fused_a16(fp, s);
+        if (ix->d_rows16 && ld % 64 == 0) vdb::launch_fused_a16(fp, s);
         else vdb::launch_fused_bf16(fp, s);
         ix->stats[3] += n;
         vdb::SelectParams mp{};
