@@ -12,9 +12,11 @@
 //    fetched both kinds could never have more row stages outstanding than query stages.  So the two kinds are fetched
 //    by DIFFERENT waves, each counting only its own kind:
 //      waves 0-3: the rows, a ring of THREE 32 KB images (two double stages = 64 KB per CU in flight); 8 pieces per
-//                 wave at every even stage, `s_waitcnt vmcnt(8)` before the barrier that publishes an even stage;
+//                 wave at every odd stage, `s_waitcnt vmcnt(8)` before the barrier that publishes an even stage;
 //      waves 4-7: the queries, a ring of THREE 16 KB images (two stages in flight, `vmcnt(4)`), and the per-row
 //                 constants of the next tile.
+//  * One barrier per stage, in the MIDDLE of the stage (see the stage loop): the LDS fragment reads run under the
+//    MFMAs instead of in front of them, and the DMA refills the images of the stage being finished.
 // All eight waves compute.  Fragments are read from LDS as bf16 (one ds_read_b128 each, no conversion in the loop).
 // Tile shape, wave layout, epilogue and sample mode are the f32-row kernel's.  Requires an even number of K stages
 // per row (padded dimension a multiple of 64); the host uses the f32-row kernel otherwise.
@@ -255,68 +257,98 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
         set_tile_ptrs(0);
         VDB_ISSUE_A(sA0, fss) VDB_ADV_A
         if (total > 2) { VDB_ISSUE_A(sA1, fss) VDB_ADV_A }
+        if (total > 4) { VDB_ISSUE_A(sA2, fss) VDB_ADV_A }
+        if (total > 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (total > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         issue_consts(0);
         VDB_ISSUE_B(sB0, bks) VDB_ADV_B
         VDB_ISSUE_B(sB1, bks) VDB_ADV_B                                 // total >= 2
+        if (total > 2) { VDB_ISSUE_B(sB2, bks) VDB_ADV_B }
+        if (total > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     }
+    __builtin_amdgcn_s_barrier();                                       // stage 0 is published
+    asm volatile("" ::: "memory");
 
-    // STEADY: the caller guarantees st + 4 < total at even stages and st + 2 < total at all, so the waits and the DMA
-    // issue are unconditional (see the f32-row kernel for why that matters to hipcc's waitcnt pass).
+    // The stage loop is software-pipelined around ONE barrier per stage that sits in the MIDDLE of the stage:
+    //     read the fragments of k-step 1 of stage s            (LDS, overlaps the next line)
+    //     8 MFMAs of k-step 0                                   (fragments read during the previous stage)
+    //     wait for this wave's pieces of stage s+1, barrier     -> stage s+1 is published, and nobody reads the images of
+    //                                                              stage s any more (every wave waited for its LDS reads)
+    //     issue the DMA of the next stages INTO THE IMAGES OF STAGE s
+    //     read the fragments of k-step 0 of stage s+1           (LDS, overlaps the next line)
+    //     8 MFMAs of k-step 1
+    // so the LDS fragment traffic (96 KB per stage and CU, ~770 clocks of LDS bandwidth) runs under the ~1000 clocks of
+    // MFMA work instead of in front of it, and the ring is one stage deeper for the same LDS: three row images hold the
+    // double stage being computed and two in flight, three query images the stage being computed and two in flight.
+    bf16x8 fa0[MT], fb0[QT];                                            // k-step 0 fragments of the stage to compute next
+#define VDB_LOAD_FRAGS(FA, FB, IA, IB, U_, T_)                                                         \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_) {                                            \
+            const u32x4 raw_ = *reinterpret_cast<const u32x4*>((IA) + a_row_off + i_ * 32 * A_ROWB + ra[U_][T_]); \
+            FA[i_] = __builtin_bit_cast(bf16x8, raw_);                                                 \
+        }                                                                                              \
+        _Pragma("unroll") for (int j_ = 0; j_ < QT; ++j_) {                                            \
+            const u32x4 raw_ = *reinterpret_cast<const u32x4*>((IB) + b_row_off + j_ * 32 * B_ROWB + rb[T_]); \
+            FB[j_] = __builtin_bit_cast(bf16x8, raw_);                                                 \
+        }                                                                                              \
+    }
+#define VDB_MFMAS(FA, FB)                                                                              \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                              \
+            _Pragma("unroll") for (int j_ = 0; j_ < QT; ++j_)                                          \
+                acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i_], FB[j_], acc[i_][j_], 0, 0, 0); \
+    }
+    if (!(p.ablate & 1u)) VDB_LOAD_FRAGS(fa0, fb0, sA0, sB0, 0, 0)
+
+    // STEADY: the caller guarantees st + 5 < total, so the waits and the DMA issue are unconditional (see the f32-row
+    // kernel for why that matters to hipcc's waitcnt pass).
     auto run_stage = [&](uint32_t st, auto pos_tag, auto steady_tag) {
         constexpr int K6 = decltype(pos_tag)::value;                    // st mod 6
         constexpr int AB = K6 >> 1;                                     // row image (two stages each)
         constexpr int U = K6 & 1;                                       // which half of the row image
         constexpr int BB = K6 % 3;                                      // query image
+        constexpr int N6 = (K6 + 1) % 6;                                // the same for stage st + 1
+        constexpr int NAB = N6 >> 1, NU = N6 & 1, NBB = N6 % 3;
         constexpr bool STEADY = decltype(steady_tag)::value;
-        const char* imgA = AB == 0 ? sA0 : AB == 1 ? sA1 : sA2;
-        char* fillA = AB == 0 ? sA2 : AB == 1 ? sA0 : sA1;              // double stage S+2 goes where double stage S-1 was
-        const char* imgB = BB == 0 ? sB0 : BB == 1 ? sB1 : sB2;
-        char* fillB = BB == 0 ? sB2 : BB == 1 ? sB0 : sB1;              // stage st+2 goes where stage st-1 was
-        // publish stage st: a row wave's pieces of an even stage's image have landed once at most the 8 pieces of the
-        // next double stage are outstanding (an odd stage reads the image its even stage published), a query wave's
-        // once at most the 4 pieces of stage st+1 are (a bare s_barrier: __syncthreads() carries a fence that hipcc
-        // lowers to vmcnt(0), which would drain the DMA pipeline at every stage; LDS writes are waited for
-        // explicitly, and the asm memory clobbers keep the compiler from moving LDS accesses across)
+        char* imgA = AB == 0 ? sA0 : AB == 1 ? sA1 : sA2;
+        char* imgB = BB == 0 ? sB0 : BB == 1 ? sB1 : sB2;
+        const char* nxtA = NAB == 0 ? sA0 : NAB == 1 ? sA1 : sA2;
+        const char* nxtB = NBB == 0 ? sB0 : NBB == 1 ? sB1 : sB2;
+        bf16x8 fa1[MT], fb1[QT];
+        if (!(p.ablate & 1u)) {
+            VDB_LOAD_FRAGS(fa1, fb1, imgA, imgB, U, 1)
+            VDB_MFMAS(fa0, fb0)
+        }
+        // publish stage st+1: a row wave's pieces of the next row image have landed once at most the 8 pieces of the
+        // double stage after it are outstanding (an even stage's successor reads the same image), a query wave's
+        // once at most the 4 pieces of stage st+2 are.  lgkmcnt(0): this wave's fragment reads of stage st are done,
+        // so after the barrier the images of stage st are free.  (A bare s_barrier: __syncthreads() carries a fence that
+        // hipcc lowers to vmcnt(0), which would drain the DMA pipeline at every stage; the asm memory clobbers keep the
+        // compiler from moving LDS accesses across.)
         if (row_wave) {
-            if (U == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            else if (STEADY || st + 2 < total) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            if (U == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (STEADY || st + 3 < total) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         } else {
-            if (STEADY || st + 1 < total) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            if (STEADY || st + 2 < total) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (row_wave) {
-            if (U == 0 && (STEADY || st + 4 < total)) { VDB_ISSUE_A(fillA, fss) VDB_ADV_A }
+            // the row image is free after its second stage: double stage S+3 goes where double stage S was
+            if (U == 1 && (STEADY || st + 5 < total)) { VDB_ISSUE_A(imgA, fss) VDB_ADV_A }
         } else {
             // constants of the NEXT tile into the other parity (every wave is past the epilogue that read it)
             if (ks == 0 && tile + 1 < ntiles) issue_consts(tile + 1);
-            if (STEADY || st + 2 < total) { VDB_ISSUE_B(fillB, bks) VDB_ADV_B }
+            if (STEADY || st + 3 < total) { VDB_ISSUE_B(imgB, bks) VDB_ADV_B }     // stage st+3 goes where stage st was
         }
-        // ---- 2 k-steps of 16: fragments -> bf16 -> 8 MFMAs each
-        const char* ap = imgA + a_row_off;
-        const char* bp = imgB + b_row_off;
-        if (!(p.ablate & 1u))
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            bf16x8 fa[MT], fb[QT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const u32x4 raw = *reinterpret_cast<const u32x4*>(ap + i * 32 * A_ROWB + ra[U][t]);
-                fa[i] = __builtin_bit_cast(bf16x8, raw);
-            }
-#pragma unroll
-            for (int j = 0; j < QT; ++j) {
-                const u32x4 raw = *reinterpret_cast<const u32x4*>(bp + j * 32 * B_ROWB + rb[t]);
-                fb[j] = __builtin_bit_cast(bf16x8, raw);
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < QT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (!(p.ablate & 1u)) {
+            if (STEADY || st + 1 < total) VDB_LOAD_FRAGS(fa0, fb0, nxtA, nxtB, NU, 0)
+            VDB_MFMAS(fa1, fb1)
         }
 
         if (ks == KS - 1 && !(p.ablate & 8u)) {
@@ -424,7 +456,7 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
     using I4 = std::integral_constant<int, 4>;
     using I5 = std::integral_constant<int, 5>;
     uint32_t st = 0;
-    for (; st + 8 < total; st += 6) {                                   // (stage index mod 6) >> 1 and mod 3 == image indices
+    for (; st + 10 < total; st += 6) {                                   // (stage index mod 6) >> 1 and mod 3 == image indices
         run_stage(st, I0{}, std::true_type{});
         run_stage(st + 1, I1{}, std::true_type{});
         run_stage(st + 2, I2{}, std::true_type{});
@@ -432,7 +464,7 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
         run_stage(st + 4, I4{}, std::true_type{});
         run_stage(st + 5, I5{}, std::true_type{});
     }
-    // the last two to eight stages (total is even): conditional issue
+    // the last two to ten stages (total is even): conditional issue
     if (st < total) { run_stage(st, I0{}, std::false_type{}); ++st; }
     if (st < total) { run_stage(st, I1{}, std::false_type{}); ++st; }
     if (st < total) { run_stage(st, I2{}, std::false_type{}); ++st; }
@@ -441,6 +473,8 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
     if (st < total) { run_stage(st, I5{}, std::false_type{}); ++st; }
     if (st < total) { run_stage(st, I0{}, std::false_type{}); ++st; }
     if (st < total) { run_stage(st, I1{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I2{}, std::false_type{}); ++st; }
+    if (st < total) { run_stage(st, I3{}, std::false_type{}); ++st; }
     if (!SAMPLE) {
         p.pool_cnt[sub_a] = pcnt_a;
         p.pool_cnt[sub_b] = pcnt_b;
@@ -452,6 +486,8 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
 #undef VDB_ISSUE_B
 #undef VDB_ADV_A
 #undef VDB_ADV_B
+#undef VDB_LOAD_FRAGS
+#undef VDB_MFMAS
 }
 
 // same tile shape, sub-pool and sample-group layout as the f32-row kernel (fused_bf16_tile_rows & co.)
