@@ -272,7 +272,7 @@ def main():
                   "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": round(gbs / PEAK_HBM_GBS, 4), "kernel_ms": round(ksh, 4),
                                "algorithmic_bytes_per_launch": sh_bytes,
-                               "kernel": "fused_a16_kernel<false> (bf16 shadow rows by LDS-DMA into a 4-image ring)"}}
+                               "kernel": "fused_a16_kernel<false> (bf16 shadow rows as full 128-byte lines by LDS-DMA: row waves fill a 3 x 32 KB ring, query waves a 3 x 16 KB ring; one mid-stage barrier per K stage)"}}
         index.set_shadow(False)
 
     # ---- the host-pointer entry point (vdb_flat_search_batch): queries cross PCIe in, results out, per batch.
