@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
             _Pragma("unroll") for (int j_ = 0; j_ < QT; ++j_)                                          \
                 acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i_], FB[j_], acc[i_][j_], 0, 0, 0); \
     }
-    if (!(p.ablate & 1u)) VDB_LOAD_FRAGS(fa0, fb0, sA0, sB0, 0, 0)
+    VDB_LOAD_FRAGS(fa0, fb0, sA0, sB0, 0, 0)
 
     // STEADY: the caller guarantees st + 5 < total, so the waits and the DMA issue are unconditional (see the f32-row
     // kernel for why that matters to hipcc's waitcnt pass).
@@ -318,10 +318,8 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
         const char* nxtA = NAB == 0 ? sA0 : NAB == 1 ? sA1 : sA2;
         const char* nxtB = NBB == 0 ? sB0 : NBB == 1 ? sB1 : sB2;
         bf16x8 fa1[MT], fb1[QT];
-        if (!(p.ablate & 1u)) {
-            VDB_LOAD_FRAGS(fa1, fb1, imgA, imgB, U, 1)
-            VDB_MFMAS(fa0, fb0)
-        }
+        VDB_LOAD_FRAGS(fa1, fb1, imgA, imgB, U, 1)
+        VDB_MFMAS(fa0, fb0)
         // publish stage st+1: a row wave's pieces of the next row image have landed once at most the 8 pieces of the
         // double stage after it are outstanding (an even stage's successor reads the same image), a query wave's
         // once at most the 4 pieces of stage st+2 are.  lgkmcnt(0): this wave's fragment reads of stage st are done,
@@ -338,17 +336,42 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        // The DMA instructions are issued BETWEEN the MFMAs of k-step 1, one piece behind each MFMA: right after the
+        // barrier all eight waves are in the same phase, and eight waves issuing 4-8 vector-memory instructions each
+        // before their first MFMA left the matrix pipe idle for that long in every stage.
+        // ONE straight-line MFMA sequence (any second copy of it on another control-flow path makes hipcc shuffle the 128
+        // accumulator registers between paths and spill); only the DMA instructions sit under (wave-uniform) branches.
+        // Every wave issues four pieces per stage: a row wave the first half of double stage S+3 at the odd stage that
+        // frees the image, the second half at the even stage after it; a query wave the four pieces of stage st+3.
+        if (STEADY || st + 1 < total) VDB_LOAD_FRAGS(fa0, fb0, nxtA, nxtB, NU, 0)
+        char* prvA = AB == 0 ? sA2 : AB == 1 ? sA0 : sA1;               // the row image of the previous double stage
+        const bool do_a = row_wave && !(p.ablate & 2u) && (U == 1 ? (STEADY || st + 5 < total) : (st > 0 && (STEADY || st + 4 < total)));
+        const bool do_b = !row_wave && !(p.ablate & 4u) && (STEADY || st + 3 < total);
+        const uint32_t la_ = (8 * (w & 3) + (U == 1 ? 0 : 4)) * 1024;
+        const uint32_t ka_ = fss * A_ROWB;
+        const uint32_t lb_ = (4 * (w & 3)) * 1024;
+        const uint32_t kb_ = bks * B_BYTES + ob;
+        // constants of the NEXT tile into the other parity (every wave is past the epilogue that read it)
+        if (!row_wave && ks == 0 && tile + 1 < ntiles) issue_consts(tile + 1);
+#define VDB_MFMA1(M_)                                                                                  \
+    acc[(M_) >> 1][(M_) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[(M_) >> 1], fb1[(M_) & 1], acc[(M_) >> 1][(M_) & 1], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);
+#define VDB_PIECE(J_)                                                                                  \
+    if (do_a) {                                                                                        \
+        const char* g_ = a_piece((U == 1 ? 0 : 4) + (J_)) + ka_;                                       \
+        VDB_DMA_NT(g_, (U == 1 ? imgA : prvA), la_ + (J_) * 1024);                                     \
+    } else if (do_b) {                                                                                 \
+        VDB_DMA(bbase + (kb_ + (J_) * 1024), imgB, lb_ + (J_) * 1024);                                 \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);
+        VDB_MFMA1(0) VDB_PIECE(0) VDB_MFMA1(1) VDB_MFMA1(2) VDB_PIECE(1) VDB_MFMA1(3)
+        VDB_MFMA1(4) VDB_PIECE(2) VDB_MFMA1(5) VDB_MFMA1(6) VDB_PIECE(3) VDB_MFMA1(7)
+#undef VDB_PIECE
+#undef VDB_MFMA1
         if (row_wave) {
-            // the row image is free after its second stage: double stage S+3 goes where double stage S was
-            if (U == 1 && (STEADY || st + 5 < total)) { VDB_ISSUE_A(imgA, fss) VDB_ADV_A }
+            if (U == 0 && st > 0 && (STEADY || st + 4 < total)) VDB_ADV_A      // both halves of the double stage are issued
         } else {
-            // constants of the NEXT tile into the other parity (every wave is past the epilogue that read it)
-            if (ks == 0 && tile + 1 < ntiles) issue_consts(tile + 1);
-            if (STEADY || st + 3 < total) { VDB_ISSUE_B(imgB, bks) VDB_ADV_B }     // stage st+3 goes where stage st was
-        }
-        if (!(p.ablate & 1u)) {
-            if (STEADY || st + 1 < total) VDB_LOAD_FRAGS(fa0, fb0, nxtA, nxtB, NU, 0)
-            VDB_MFMAS(fa1, fb1)
+            if (STEADY || st + 3 < total) VDB_ADV_B
         }
 
         if (ks == KS - 1 && !(p.ablate & 8u)) {
