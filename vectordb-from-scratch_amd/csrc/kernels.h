@@ -169,6 +169,7 @@ struct FusedBf16Params {
 };
 void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s);
 void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s);
+void launch_fused_bf16p(const FusedBf16Params& p, hipStream_t s);     // kernels_fused_bf16p.hip: the filter pass, software-pipelined (default)
 void launch_fused_a16(const FusedBf16Params& p, hipStream_t s);      // the filter pass reading p.rows16 (ld % 64 == 0)
 uint32_t fused_bf16_tile_rows();
 uint32_t fused_bf16_subpools_per_query(uint32_t n_wg);

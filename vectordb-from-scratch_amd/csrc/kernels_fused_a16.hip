@@ -412,10 +412,14 @@ __global__ __launch_bounds__(NT, 2) void fused_a16_kernel(FusedBf16Params p) {
                     const float4 a4 = *reinterpret_cast<const float4*>(al + i * 32 + 8 * j);
                     const float4 b4 = *reinterpret_cast<const float4*>(be + i * 32 + 8 * j);
                     // scores of 4 rows x 2 queries
-                    const float sa0 = fmaf(acc[i][0][4 * j + 0], a4.x, b4.x), sa1 = fmaf(acc[i][0][4 * j + 1], a4.y, b4.y);
-                    const float sa2 = fmaf(acc[i][0][4 * j + 2], a4.z, b4.z), sa3 = fmaf(acc[i][0][4 * j + 3], a4.w, b4.w);
-                    const float sb0 = fmaf(acc[i][1][4 * j + 0], a4.x, b4.x), sb1 = fmaf(acc[i][1][4 * j + 1], a4.y, b4.y);
-                    const float sb2 = fmaf(acc[i][1][4 * j + 2], a4.z, b4.z), sb3 = fmaf(acc[i][1][4 * j + 3], a4.w, b4.w);
+                    // (two rows per v_pk_fma_f32: the same IEEE fma per element, half the instructions)
+                    const f32x2 al01 = {a4.x, a4.y}, al23 = {a4.z, a4.w}, be01 = {b4.x, b4.y}, be23 = {b4.z, b4.w};
+                    const f32x2 pa01 = {acc[i][0][4 * j + 0], acc[i][0][4 * j + 1]}, pa23 = {acc[i][0][4 * j + 2], acc[i][0][4 * j + 3]};
+                    const f32x2 pb01 = {acc[i][1][4 * j + 0], acc[i][1][4 * j + 1]}, pb23 = {acc[i][1][4 * j + 2], acc[i][1][4 * j + 3]};
+                    const f32x2 ra01 = __builtin_elementwise_fma(pa01, al01, be01), ra23 = __builtin_elementwise_fma(pa23, al23, be23);
+                    const f32x2 rb01 = __builtin_elementwise_fma(pb01, al01, be01), rb23 = __builtin_elementwise_fma(pb23, al23, be23);
+                    const float sa0 = ra01.x, sa1 = ra01.y, sa2 = ra23.x, sa3 = ra23.y;
+                    const float sb0 = rb01.x, sb1 = rb01.y, sb2 = rb23.x, sb3 = rb23.y;
                     const uint32_t rt0 = rowb + 8 * j;                  // tile-row of element 0
                     if (SAMPLE) {
                         // smallest score of the lane's eligible rows (v_min_f32 skips a NaN score: such a row is no witness

@@ -118,6 +118,7 @@ struct vdb_flat_index {
     // device store
     uint16_t* d_rows16 = nullptr;         // opt-in bf16 shadow of d_rows [cap_rows][ld] (vdb_flat_set_shadow), else null
     bool shadow = false;
+    bool fused_pipe = true;               // filter pass: software-pipelined kernel (VDB_FUSED_PIPE=0: the unpipelined one, A/B runs)
     float* d_rows = nullptr; float* d_nd = nullptr; float* d_alpha = nullptr; float* d_beta = nullptr;
     uint64_t* d_row_ids = nullptr; uint32_t* d_live = nullptr; uint32_t* d_scalars = nullptr;  // [0]=nd2max bits [1]=zero count [2],[3]=max bf16 rounding error of a row (abs^2, rel^2)
     uint32_t cap_rows = 0;
@@ -613,6 +614,7 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
 
         if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
         if (a16) vdb::launch_fused_a16(fp, s);
+        else if (ix->fused_pipe) vdb::launch_fused_bf16p(fp, s);
         else vdb::launch_fused_bf16(fp, s);
         if (ix->profile) {
             HIP_TRY(hipEventRecord(ix->ev1, s));
@@ -695,6 +697,7 @@ int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
         fp.thr = ix->w2_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
         if (ix->d_rows16 && ld % 64 == 0) vdb::launch_fused_a16(fp, s);
+        else if (ix->fused_pipe) vdb::launch_fused_bf16p(fp, s);
         else vdb::launch_fused_bf16(fp, s);
         ix->stats[3] += n;
         vdb::SelectParams mp{};
@@ -1069,6 +1072,7 @@ int vdb_flat_create(int metric, int device, vdb_flat_index** out) {
     ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char* e = getenv("VDB_SCREEN")) ix->screen = strcmp(e, "f32") != 0 && strcmp(e, "0") != 0;
     if (const char* e = getenv("VDB_SHADOW")) ix->shadow = strcmp(e, "0") != 0;
+    if (const char* e = getenv("VDB_FUSED_PIPE")) ix->fused_pipe = strcmp(e, "0") != 0;
     if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ix;
         return fail(VDB_ERR_DEVICE, "hipStreamCreate failed");
