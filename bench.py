@@ -205,8 +205,8 @@ def main():
     if screened:
         roofline = {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(achieved_gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
-                    "kernel": "fused_bf16_kernel<false> (8 waves, 256 rows x 256 queries, f32 rows by LDS-DMA into a 3-image "
-                              "ring, bf16 MFMA 32x32x16 scores, threshold filter)",
+                    "kernel": "fused_bf16p_kernel<false> (8 waves, 256 rows x 256 queries, f32 rows by LDS-DMA into a 3-image "
+                              "ring, one mid-stage barrier per K stage, bf16 MFMA 32x32x16 scores, threshold filter)",
                     "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
                     "algorithmic_flops_per_launch": alg_flops,
                     "bf16_mfma_tflops": round(achieved_tf, 1)}
