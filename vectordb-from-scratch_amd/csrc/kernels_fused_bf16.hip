@@ -24,6 +24,9 @@
 // lane keeps the smallest (score,row) key of the 64 rows it owns per query ("group minimum").  The kp-th
 // smallest of a query's group minima is an inclusive threshold that at least kp rows meet, and the
 // instruction sequence per (row, query) is identical in both modes, so the scores agree bit for bit.
+// NOTE: the FILTER pass runs by default in its software-pipelined form, kernels_fused_bf16p.hip (same tile, same DMA
+// plan, same epilogue; one mid-stage barrier per stage); this file keeps the sample pass and the unpipelined filter
+// pass (VDB_FUSED_PIPE=0).
 #include "kernels.h"
 
 #include <type_traits>
