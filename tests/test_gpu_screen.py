@@ -293,3 +293,30 @@ def test_shadow_copy_follows_adds_growth_and_toggling(vdb):
     finally:
         if shadow_on():
             os.environ["VDB_SHADOW"] = "1"
+
+
+def test_pipelined_and_unpipelined_filter_pass_agree(vdb):
+    """kernels_fused_bf16p.hip (default) against the unpipelined filter pass of kernels_fused_bf16.hip (VDB_FUSED_PIPE=0 at
+    handle creation): same operands and the same MFMA order per accumulator, so the scores -- and with them the candidate
+    pools, the tier counters and the results -- are identical, including a ragged last tile and tombstones."""
+    rng = np.random.default_rng(4242)
+    n, d, nq, k = 123_457, 200, 77, 10
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    res, stats = [], []
+    for pipe in ("1", "0"):
+        os.environ["VDB_FUSED_PIPE"] = pipe
+        try:
+            ix = make_index(vdb, 0, rows)
+        finally:
+            os.environ.pop("VDB_FUSED_PIPE", None)
+        for r in range(0, 3000, 7):
+            ix.remove(r)
+        res.append(ix.search_batch_arrays(q, k))
+        st = ix.last_stats()
+        stats.append({x: st[x] for x in ("bf16_screen", "uncertified", "f32_tier_queries", "rethreshold_queries", "pool_overflows", "exact_queries")})
+    assert stats[0]["bf16_screen"] == 1 and stats[0] == stats[1], stats
+    assert same(res[0], res[1])
+    live = np.ones(n, dtype=np.uint8)
+    live[0:3000:7] = 0
+    check_oracle(0, rows, q, k, res[0], [0, 40, nq - 1], live=live)
