@@ -74,8 +74,8 @@ def index_ld(dim):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rows", type=int, default=N_ROWS, help="override the index size (parity/debug only)")
     ap.add_argument("--dim", type=int, default=DIM)
     ap.add_argument("--batch", type=int, default=BATCH)

@@ -173,6 +173,13 @@ def gpu_local_search(index, mask_ptr=0, mask_bits=0, reuse_outputs=False):
     returns the same three output tensors on every call (overwritten by the next search)."""
     cache = {}
 
+    def _stream_of(dev):
+        # the caller's current stream, through the raw accessor (torch.cuda.current_stream builds a Stream object: ~10 us)
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        if raw is not None:
+            return int(raw(dev.index if dev.index is not None else torch.cuda.current_device()))
+        return torch.cuda.current_stream(dev).cuda_stream
+
     def run(queries, k, outs=None):
         B, d = queries.shape
         dev = queries.device
@@ -188,15 +195,14 @@ def gpu_local_search(index, mask_ptr=0, mask_bits=0, reuse_outputs=False):
             if reuse_outputs:
                 cache[key] = (ids, dists, counts)
         index.search_batch_device(queries.data_ptr(), B, d, k, ids.data_ptr(), dists.data_ptr(), counts.data_ptr(),
-                                  stream=torch.cuda.current_stream(dev).cuda_stream, mask_ptr=mask_ptr,
-                                  mask_bits=mask_bits)
+                                  stream=_stream_of(dev), mask_ptr=mask_ptr, mask_bits=mask_bits)
         return ids, dists, counts
 
     def begin(queries, k, outs, code_ptr):
         B, d = queries.shape
         ids, dists, counts = outs
         index.search_batch_device_begin(queries.data_ptr(), B, d, k, ids.data_ptr(), dists.data_ptr(), counts.data_ptr(),
-                                        code_ptr=code_ptr, stream=torch.cuda.current_stream(queries.device).cuda_stream,
+                                        code_ptr=code_ptr, stream=_stream_of(queries.device),
                                         mask_ptr=mask_ptr, mask_bits=mask_bits)
 
     run.begin = begin
