@@ -128,7 +128,7 @@ struct vdb_flat_index {
     // search workspace
     DevBuf<float> w_qp, w_qnorm, w_thr, w_qin, w_outd, w_qerr;
     DevBuf<uint64_t> w_dense, w_samp, w_pool, w_cand, w_exact, w_exsel, w_mask_ids, w_outi;
-    DevBuf<uint32_t> w_cnt, w_rowmask, w_flags, w_outc, w_subcnt;
+    DevBuf<uint32_t> w_cnt, w_rowmask, w_flags, w_outc, w_subcnt, w_depth;
     DevBuf<uint16_t> w_qb;                                  // bf16 copy of the padded queries (screening tier)
     // compact block of the queries the screening tier could not certify (re-run by the f32 tier)
     DevBuf<float> w2_qp, w2_qnorm, w2_thr, w2_outd, w2_qerr;
@@ -643,7 +643,23 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         rp.qerr = ix->w_qerr.p + q0; rp.c_acc = c_acc_bf16(ix);
         rp.kp_first = round_up((uint32_t)k + 38u, 16u); rp.kp_step = 32;
         rp.thr_next = d_thr_next ? d_thr_next + q0 : nullptr;
+        // diagnostics: VDB_KP_FIRST overrides the first re-rank round, VDB_RR_DEPTH prints the depth each query ended at
+        static const char* e_first = getenv("VDB_KP_FIRST");
+        if (e_first) rp.kp_first = (uint32_t)std::max(1, atoi(e_first));
+        static const bool dump_depth = getenv("VDB_RR_DEPTH") != nullptr;
+        if (dump_depth) {
+            if ((rc = ix->w_depth.ensure(SUPER))) return rc;
+            rp.depth = ix->w_depth.p;
+        }
         vdb::launch_rerank(rp, nb, s);
+        if (dump_depth) {
+            std::vector<uint32_t> dep(nb);
+            HIP_TRY(hipMemcpyAsync(dep.data(), ix->w_depth.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            std::sort(dep.begin(), dep.end());
+            fprintf(stderr, "[vdb] re-rank depth of %u queries: min %u  p25 %u  median %u  p75 %u  p95 %u  max %u  (first round %u)\n", nb,
+                    dep[0], dep[nb / 4], dep[nb / 2], dep[(size_t)nb * 3 / 4], dep[(size_t)nb * 95 / 100], dep[nb - 1], rp.kp_first);
+        }
     }
     return VDB_OK;
 }
@@ -1099,7 +1115,7 @@ void vdb_flat_destroy(vdb_flat_index* ix) {
     ix->w_qb.release(); ix->w_qerr.release(); ix->w2_qp.release(); ix->w2_qnorm.release(); ix->w2_thr.release(); ix->w2_outd.release();
     ix->w2_qerr.release(); ix->w2_cand.release(); ix->w2_qb.release();
     ix->w2_outi.release(); ix->w2_outc.release(); ix->w2_flags.release(); ix->w2_qidx.release();
-    ix->w_cnt.release(); ix->w_subcnt.release(); ix->w_rowmask.release(); ix->w_flags.release(); ix->w_outc.release();
+    ix->w_cnt.release(); ix->w_subcnt.release(); ix->w_rowmask.release(); ix->w_flags.release(); ix->w_outc.release(); ix->w_depth.release();
     if (ix->h_flags) (void)hipHostFree(ix->h_flags);
     if (ix->h_pairs) (void)hipHostFree(ix->h_pairs);
     if (ix->h_pout) (void)hipHostFree(ix->h_pout);
