@@ -165,7 +165,7 @@ struct FusedBf16Params {
     // sample mode: n_sample = 2^sample_shift <= n_rows, sample j -> row (j*n_rows) >> sample_shift; per query and
     // group of 64 sample rows the smallest key
     uint32_t n_sample, sample_shift, sample_block; uint64_t* minkeys; uint32_t minkey_stride;   // minkeys[q*minkey_stride + group]
-    uint32_t ablate;                                   // diagnostics only (VDB_BF16_ABLATE): 1 skip LDS reads + MFMAs, 2 skip the row DMA, 4 skip the query DMA, 8 skip the epilogue
+    uint32_t ablate;                                   // diagnostics only (VDB_BF16_ABLATE): 1 skip LDS reads + MFMAs (unpipelined kernel only), 2 skip the row DMA, 4 skip the query DMA, 8 skip the epilogue
 };
 void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s);
 void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s);
