@@ -74,6 +74,10 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
     __shared__ __attribute__((aligned(16))) float sAlpha[2 * TR];
     __shared__ __attribute__((aligned(16))) float sBeta[2 * TR];
     __shared__ __attribute__((aligned(16))) uint32_t sMaskW[2 * TR];
+    // sample mode: the device rows of the (single) tile's scattered sample rows live here instead of in four 64-bit address
+    // registers per lane (with those the sample instance spilled in its last stages, and every scratch reload is a
+    // vmcnt(0) -- a drain of the DMA pipeline); each lane reads back only what it wrote
+    __shared__ uint32_t sRow[SAMPLE ? 32 * 64 : 1];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -173,8 +177,13 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t row = tile_rows_of(t, 32 * w + 8 * j + a_pr);
-            aptr[j] = rows_b + (size_t)row * ld * 4 + a_chunk[j];
+            if (SAMPLE) sRow[(4 * w + j) * 64 + lane] = row;
+            else aptr[j] = rows_b + (size_t)row * ld * 4 + a_chunk[j];
         }
+    };
+    auto a_piece = [&](int j) -> const char* {
+        if (SAMPLE) return rows_b + (size_t)sRow[(4 * w + j) * 64 + lane] * ld * 4 + a_chunk[j];
+        return aptr[j];
     };
     // The LDS-DMA is issued from inline asm, not through __builtin_amdgcn_global_load_lds: hipcc's waitcnt pass
     // tracks the builtin as a pending LDS write and, at the loop header of the 3-stage ring, cannot bound how many
@@ -196,10 +205,11 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
         const uint32_t ka_ = (KSI) * (KSTAGE * 4);                                                     \
         const uint32_t kb_ = (KSI) * B_BYTES;                                                          \
         if (!(p.ablate & 2u)) {                                                                        \
-        VDB_DMA_NT(aptr[0] + ka_, IMG, la_);                                                           \
-        VDB_DMA_NT(aptr[1] + ka_, IMG, la_ + 1024);                                                    \
-        VDB_DMA_NT(aptr[2] + ka_, IMG, la_ + 2048);                                                    \
-        VDB_DMA_NT(aptr[3] + ka_, IMG, la_ + 3072);                                                    \
+        const char *g0_ = a_piece(0) + ka_, *g1_ = a_piece(1) + ka_, *g2_ = a_piece(2) + ka_, *g3_ = a_piece(3) + ka_; \
+        VDB_DMA_NT(g0_, IMG, la_);                                                                     \
+        VDB_DMA_NT(g1_, IMG, la_ + 1024);                                                              \
+        VDB_DMA_NT(g2_, IMG, la_ + 2048);                                                              \
+        VDB_DMA_NT(g3_, IMG, la_ + 3072);                                                              \
         }                                                                                              \
         if (!(p.ablate & 4u)) {                                                                        \
         VDB_DMA(bbase + (ob[0] + kb_), IMG, lb_);                                                      \
