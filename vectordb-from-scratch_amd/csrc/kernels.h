@@ -114,6 +114,7 @@ struct SelectParams {
     // gather mode (n_sub > 0): the query's keys live in n_sub sub-pools of capacity capl,
     // keys[(q*n_sub + s)*capl + j], j < sub_counts[q*n_sub + s]
     const uint32_t* sub_counts; uint32_t n_sub; uint32_t capl;
+    uint32_t wg_major;                                 // 1: the keys of sub-pool i = wg*4 + r of query q are at ((wg*256 + q)*4 + r)*capl (bf16 tier)
     uint32_t kk;                                       // how many smallest keys to keep (<= 2048)
     uint64_t* out_keys; uint32_t out_stride;           // sorted ascending, padded with EMPTY_KEY
     uint32_t* out_cnt;
@@ -165,7 +166,7 @@ struct FusedBf16Params {
     // sample mode: n_sample = 2^sample_shift <= n_rows, sample j -> row (j*n_rows) >> sample_shift; per query and
     // group of 64 sample rows the smallest key
     uint32_t n_sample, sample_shift, sample_block; uint64_t* minkeys; uint32_t minkey_stride;   // minkeys[q*minkey_stride + group]
-    uint32_t ablate;                                   // diagnostics only (VDB_BF16_ABLATE): 1 skip LDS reads + MFMAs (unpipelined kernel only), 2 skip the row DMA, 4 skip the query DMA, 8 skip the epilogue
+    uint32_t ablate;                                   // diagnostics only (VDB_BF16_ABLATE): 1 skip LDS reads + MFMAs (unpipelined kernel only), 2 skip the row DMA, 4 skip the query DMA, 8 skip the epilogue, 16 (pipelined kernel) thresholds = -inf: nothing passes the filter
 };
 void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s);
 void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s);

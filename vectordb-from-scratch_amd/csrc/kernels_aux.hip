@@ -387,7 +387,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
             if (lane == 63 && incl) wbase = atomicAdd(&sN, incl);
             wbase = __shfl(wbase, 63);
             uint32_t pos = wbase + incl - c;
-            const uint64_t* src = base + (size_t)i * p.capl;
+            // (bf16 tier: keys workgroup-major, sub-pool i = wg*4 + r of query q at ((wg*256 + q)*4 + r)*capl)
+            const uint64_t* src = p.wg_major ? p.keys + (((size_t)(i >> 2) * 256u + q) * 4u + (i & 3u)) * p.capl : base + (size_t)i * p.capl;
             for (uint32_t j0 = 0; j0 < c; j0 += 4) {
                 uint64_t k[4];
 #pragma unroll

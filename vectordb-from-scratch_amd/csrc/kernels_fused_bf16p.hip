@@ -95,12 +95,17 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
     if (!SAMPLE) {
         sub_a = (((size_t)q_a * p.n_wg + blockIdx.x) * 2 + wr) * 2 + h;
         sub_b = (((size_t)q_b * p.n_wg + blockIdx.x) * 2 + wr) * 2 + h;
-        pool_a = p.pool + sub_a * p.capl;
-        pool_b = p.pool + sub_b * p.capl;
+        // The pool KEYS are laid out workgroup-major -- slot ((wg*256 + q)*4 + row half*2 + lane half)*capl -- so that the
+        // few scattered appends of one workgroup fall into ONE 2 MB region instead of one region per query (256 regions
+        // 2 MB apart: every append then missed the CU's address-translation cache in front of the row stream).  The
+        // counts stay query-major (pool_cnt[sub]); the select's gather knows both layouts (SelectParams::wg_major).
+        pool_a = p.pool + ((((size_t)blockIdx.x * TQ + q_a) * 2 + wr) * 2 + h) * p.capl;
+        pool_b = p.pool + ((((size_t)blockIdx.x * TQ + q_b) * 2 + wr) * 2 + h) * p.capl;
         thr_a = p.thr[q_a];
         thr_b = p.thr[q_b];
         // consume the two loads here: a first use inside the stage loop would get a compiler-inserted vmcnt(0)
         // there, i.e. a wait for every DMA in flight, once per tile
+        if (p.ablate & 16u) thr_a = thr_b = -__builtin_inff();       // diagnostics: nothing passes the filter (cost of the append path)
         asm volatile("" : "+v"(thr_a), "+v"(thr_b));
     }
     uint32_t pcnt_a = 0, pcnt_b = 0;
@@ -391,20 +396,24 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
                                                       __builtin_amdgcn_ballot_w64(!(sa2 > thr_a)) | __builtin_amdgcn_ballot_w64(!(sa3 > thr_a));
                         const unsigned long long mb = __builtin_amdgcn_ballot_w64(!(sb0 > thr_b)) | __builtin_amdgcn_ballot_w64(!(sb1 > thr_b)) |
                                                       __builtin_amdgcn_ballot_w64(!(sb2 > thr_b)) | __builtin_amdgcn_ballot_w64(!(sb3 > thr_b));
-#define VDB_PUSH(E, S, THR, POOL, PCNT)                                                                \
-    if (!((S) > (THR)) && ((vbits >> (8 * j + (E))) & 1u)) {                                           \
-        if (PCNT < p.capl) POOL[PCNT] = make_raw_key((S), tr0 + rt0 + (E));                            \
-        ++PCNT;                                                                                        \
+                        // The append path is what the epilogue costs (with thresholds that let nothing pass the kernel is as
+                        // fast as without an epilogue), so it is kept short: one 4-bit hit mask per lane and query, then a
+                        // loop over its set bits -- typically one lane, one iteration -- instead of four masked regions.
+#define VDB_APPEND(S0, S1, S2, S3, THR, POOL, PCNT)                                                    \
+    {                                                                                                  \
+        uint32_t hm_ = (!((S0) > (THR)) ? 1u : 0u) | (!((S1) > (THR)) ? 2u : 0u) | (!((S2) > (THR)) ? 4u : 0u) | (!((S3) > (THR)) ? 8u : 0u); \
+        hm_ &= (vbits >> (8 * j)) & 0xfu;                                                              \
+        while (hm_) {                                                                                  \
+            const uint32_t e_ = (uint32_t)__builtin_ctz(hm_);                                          \
+            hm_ &= hm_ - 1u;                                                                           \
+            const float sc_ = e_ == 0 ? (S0) : e_ == 1 ? (S1) : e_ == 2 ? (S2) : (S3);                 \
+            if (PCNT < p.capl) POOL[PCNT] = make_raw_key(sc_, tr0 + rt0 + e_);                         \
+            ++PCNT;                                                                                    \
+        }                                                                                              \
     }
-                        if (__builtin_expect(ma != 0ull, 0)) {
-                            VDB_PUSH(0, sa0, thr_a, pool_a, pcnt_a) VDB_PUSH(1, sa1, thr_a, pool_a, pcnt_a)
-                            VDB_PUSH(2, sa2, thr_a, pool_a, pcnt_a) VDB_PUSH(3, sa3, thr_a, pool_a, pcnt_a)
-                        }
-                        if (__builtin_expect(mb != 0ull, 0)) {
-                            VDB_PUSH(0, sb0, thr_b, pool_b, pcnt_b) VDB_PUSH(1, sb1, thr_b, pool_b, pcnt_b)
-                            VDB_PUSH(2, sb2, thr_b, pool_b, pcnt_b) VDB_PUSH(3, sb3, thr_b, pool_b, pcnt_b)
-                        }
-#undef VDB_PUSH
+                        if (__builtin_expect(ma != 0ull, 0)) VDB_APPEND(sa0, sa1, sa2, sa3, thr_a, pool_a, pcnt_a)
+                        if (__builtin_expect(mb != 0ull, 0)) VDB_APPEND(sb0, sb1, sb2, sb3, thr_b, pool_b, pcnt_b)
+#undef VDB_APPEND
                     }
                 }
             }

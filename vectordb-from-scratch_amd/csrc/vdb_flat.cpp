@@ -627,7 +627,7 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
 
         vdb::SelectParams mp{};
         mp.keys = ix->w_pool.p; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
-        mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl;
+        mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl; mp.wg_major = 1;
         mp.kk = kp; mp.out_keys = ix->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
         mp.out_thr = nullptr; mp.ovf = d_ovf + q0; mp.summary = d_status + 1;
         vdb::launch_select(mp, nb, s);
@@ -717,7 +717,7 @@ int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo
         else vdb::launch_fused_bf16(fp, s);
         ix->stats[3] += n;
         vdb::SelectParams mp{};
-        mp.keys = ix->w_pool.p; mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl;
+        mp.keys = ix->w_pool.p; mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl; mp.wg_major = 1;
         mp.kk = KMAX; mp.out_keys = ix->w2_cand.p; mp.out_stride = KMAX; mp.out_cnt = d_cand_cnt;
         mp.ovf = d_ovf2 + q0; mp.summary = nullptr; mp.flag_truncation = 1;
         vdb::launch_select(mp, nb, s);
