@@ -84,7 +84,6 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-f32-tier", action="store_true", help="skip the side measurement of the f32 MFMA tier")
-    ap.add_argument("--no-shadow", action="store_true", help="skip the side measurement of the opt-in bf16 shadow copy (vdb_flat_set_shadow)")
     ap.add_argument("--data", default="uniform", choices=["uniform", "gauss"], help="uniform[0,1) (the reference benches' distribution) or unit-normalised Gaussian rows")
     ap.add_argument("--screen", type=int, default=1, help="1: bf16 screening tier first (default); 0: f32 MFMA tier only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
@@ -243,38 +242,6 @@ def main():
                                  "kernel": "fused_score_filter_dma3_kernel (f32-input MFMA 32x32x2, 3-image LDS-DMA ring)"}}
         index.set_screen(1)
 
-    # ---- the opt-in bf16 shadow copy of the rows (vdb_flat_set_shadow: +50 % HBM, the screening pass streams 2 bytes per
-    # element instead of 4; same scores, same results).  Measured beside the headline, never as `value`.
-    shadow = None
-    if screened and not args.no_shadow and dim > 32:
-        index.set_shadow(True)
-        for _ in range(2):
-            step()
-        barrier()
-        t1 = time.perf_counter()
-        n_sh = max(3, min(args.steps, 20))
-        for _ in range(n_sh):
-            out_sh = step()
-        barrier()
-        el = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=device)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            el = float(t.item())
-        st_sh = index.last_stats()
-        ksh = kernel_ms_of(3)
-        sh_bytes = 2.0 * local_rows * dim + 2.0 * b_launch * dim
-        gbs = sh_bytes / (ksh * 1e-3) / 1e9 if ksh > 0 else 0.0
-        same = bool(torch.equal(out_sh[0], out[0]) and torch.equal(out_sh[1].view(torch.int32), out[1].view(torch.int32)))
-        shadow = {"value": round(B * n_sh / el, 2), "unit": "queries/s", "ms_per_step": round(1e3 * el / n_sh, 4),
-                  "results_identical_to_default_path": same, "used": bool(st_sh.get("bf16_shadow")),
-                  "extra_hbm_bytes": 2 * local_rows * index_ld(dim),
-                  "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": round(gbs / PEAK_HBM_GBS, 4), "kernel_ms": round(ksh, 4),
-                               "algorithmic_bytes_per_launch": sh_bytes,
-                               "kernel": "fused_a16_kernel<false> (bf16 shadow rows as full 128-byte lines by LDS-DMA: row waves fill a 3 x 32 KB ring, query waves a 3 x 16 KB ring; one mid-stage barrier per K stage)"}}
-        index.set_shadow(False)
-
     # ---- the host-pointer entry point (vdb_flat_search_batch): queries cross PCIe in, results out, per batch.
     # Reported beside the headline, never as `value`.
     host_io = None
@@ -355,7 +322,6 @@ def main():
             "path_stats": stats,
             "roofline": roofline,
             "f32_mfma_tier": f32_tier,
-            "bf16_shadow_rows": shadow,
             "pcie_inclusive": host_io,
             "cpu_baseline": cpu,
         }

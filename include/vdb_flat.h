@@ -192,7 +192,9 @@ int vdb_flat_last_stats(const vdb_flat_index *h, uint64_t out[8]);
  *  [10] [11] [12] host clock of the call, ns: first tier enqueued / its flags on the host / return
  *  [13] queries answered by the re-threshold pass (a second screening pass whose thresholds are the score cuts that the
  *       k-th exact distances of the first pass imply; every key under the cut is re-ranked)
- *  [14] 1 when the screening pass read the bf16 shadow copy of the rows (vdb_flat_set_shadow)
+ *  [14] (unused, 0)
+ *  [15] 1 when the library is the DIAGNOSTICS build (-DVDB_DIAG) and one of its environment knobs is set: such a run
+ *       is not covered by the exactness guarantee.  Always 0 in the release library, which reads no environment.
  * With the screening tier on, [4] [5] [7] describe ITS sample, k' and kernel time. */
 int vdb_flat_last_stats_ex(const vdb_flat_index *h, uint64_t *out, size_t n);
 
@@ -201,19 +203,16 @@ int vdb_flat_last_stats_ex(const vdb_flat_index *h, uint64_t *out, size_t n);
  *     query, re-ranks them with the reference's exact f32 arithmetic (distance.rs:37-73) and certifies the
  *     result with a rigorous bound on the bf16 rounding error; uncertified queries go to the f32 tier;
  *  0: the f32-input MFMA tier only (v_mfma_f32_32x32x2_f32, arithmetic-bound), then the exact scan.
- * The environment variable VDB_SCREEN=f32 selects 0 for every handle created afterwards. */
+ */
 int vdb_flat_set_screen(vdb_flat_index *h, int mode);
 
-/* Opt-in bf16 SHADOW COPY of the rows for the screening tier (no reference counterpart; results are identical either
- * way).  on = 1 keeps, next to the f32 rows, their bf16 rounding (2 more bytes per element of HBM: +50 %); the screening
- * pass then streams the shadow -- half the bytes of the HBM-bound pass -- and computes exactly the scores it computes
- * from the f32 rows (the same RNE conversion, done once at upload instead of in the kernel).  The exact re-rank, the
- * certificates and every fallback tier keep reading the f32 rows.  Existing rows are converted by the call, later adds
- * maintain the shadow; on = 0 frees it.  VDB_SHADOW=1 turns it on for every handle created afterwards.  The
- * shadow is read when the dimension, padded to a multiple of 32, is a multiple of 64 (768, 1536, 128, 100 ...); other
- * dimensions are screened from the f32 rows.  vdb_flat_last_stats_ex()[14] = 1 when the last search screened from the
- * shadow. */
-int vdb_flat_set_shadow(vdb_flat_index *h, int on);
+/* Test hook (no reference counterpart; results are identical whatever the flags): force the hand-over of queries to
+ * the slower tiers so that every tier can be compared with every other on the same index.  Not read from the
+ * environment -- the release library has no getenv on any path. */
+#define VDB_TIERS_NO_RETHRESHOLD 1u /* skip the re-threshold pass: uncertified queries go straight to the f32 MFMA tier */
+#define VDB_TIERS_FORCE_F32 2u      /* hand EVERY query the screening tier answered to the f32 MFMA tier as well */
+#define VDB_TIERS_FORCE_EXACT 4u    /* hand every query to the exact scan */
+int vdb_flat_set_tiers(vdb_flat_index *h, unsigned flags);
 
 /* Thread-local message of the last failing call on this thread, plus the
  * DimensionMismatch pair (error.rs:12-13).  Any pointer may be NULL. */

@@ -10,7 +10,7 @@
  * traversal asks for (graph.rs:155, :182, :224) is evaluated on the MI355X, in the reference's exact f32 operation
  * order (distance.rs:37-73).  Searches run DEVICE-RESIDENT by default (kernels_hnsw.hip): the graph is mirrored in HBM
  * and one workgroup per query walks it, with the reference's priority queues in LDS -- one launch per batch; what does
- * not fit that kernel (m > 19, ef > 1022, a walk that overflows its LDS structures, VDB_HNSW_HOST=1) is traversed on
+ * not fit that kernel (m > 19, ef > 1022, a walk that overflows its LDS structures, vdb_hnsw_set_traversal) is traversed on
  * the host with the candidate lists of ALL in-flight queries evaluated in one launch per traversal round.  Both give
  * the reference's results; there is no CPU distance path.
  *
@@ -51,6 +51,10 @@ int vdb_hnsw_remove(vdb_hnsw_index *h, uint64_t id);
  * Outputs [nq][k]; out_counts[b] <= k results, ascending by distance. */
 int vdb_hnsw_search_batch(vdb_hnsw_index *h, const float *queries, size_t nq, size_t dim, size_t k, size_t ef,
                           uint64_t *out_ids, float *out_dists, size_t *out_counts);
+
+/* Test hook (results are identical either way): host_only = 1 sends every search through the host traversal instead of
+ * the device-resident walk; host_threads > 0 fixes its worker-thread count (0 = automatic).  Not read from the environment. */
+int vdb_hnsw_set_traversal(vdb_hnsw_index *h, int host_only, size_t host_threads);
 
 size_t vdb_hnsw_len(const vdb_hnsw_index *h);                              /* graph.rs:109-111 */
 int vdb_hnsw_metric(const vdb_hnsw_index *h);

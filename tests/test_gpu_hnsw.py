@@ -85,19 +85,12 @@ def test_device_resident_and_host_traversal_agree(vdb):
     g2, o2, _ = build_pair(vdb, 0, rows, 24, 100, 50, seed=2)
     assert_same_results(g2, o2, q[:9], 10, 64)
     assert g2.stats()["device_queries"] == 0 and g2.stats()["last_search_rounds"] > 0
-    # VDB_HNSW_HOST=1 is read once per process: a child process runs the same batch on the host path
-    code = ("import numpy as np, sys; sys.path.insert(0, %r); from conftest import load_package; vdb = load_package();"
-            "rng = np.random.default_rng(12); rows = rng.random((3000, 40), dtype=np.float32); q = rng.random((64, 40), dtype=np.float32);"
-            "g = vdb.GpuHnswIndex(vdb.DistanceMetric(0), vdb.HnswParams.new(16, 100, 50), seed=2);"
-            "g.build_batch((np.arange(3000, dtype=np.uint64), rows)); i, d, c = g.search_batch_arrays(q, 10, 200);"
-            "assert g.stats()['device_queries'] == 0; np.save(sys.argv[1], i); np.save(sys.argv[2], d.view(np.uint32))") % os.path.dirname(__file__)
-    import tempfile
-    with tempfile.TemporaryDirectory() as td:
-        a, b = os.path.join(td, "i.npy"), os.path.join(td, "d.npy")
-        env = dict(os.environ, VDB_HNSW_HOST="1")
-        out = subprocess.run([sys.executable, "-c", code, a, b], env=env, capture_output=True, text=True, timeout=300)
-        assert out.returncode == 0, out.stderr[-2000:]
-        assert np.array_equal(np.load(a), gi) and np.array_equal(np.load(b), gd.view(np.uint32))
+    # the host traversal forced for the same batch (vdb_hnsw_set_traversal): identical results
+    g.set_traversal(host_only=True, host_threads=3)
+    hi, hd, hc = g.search_batch_arrays(q, 10, 200)
+    assert g.stats()["device_queries"] == 64 and g.stats()["last_search_rounds"] > 0
+    assert np.array_equal(hi, gi) and np.array_equal(hd.view(np.uint32), gd.view(np.uint32)) and np.array_equal(hc, gc)
+    g.set_traversal(host_only=False)
 
 
 def test_single_adds_equal_bulk_build(vdb):

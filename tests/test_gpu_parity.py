@@ -164,12 +164,10 @@ def test_forced_exact_fallback_matches(vdb):
     q = rng.standard_normal((9, 40)).astype(np.float32)
     ix = make_index(vdb, 0, rows)
     a = ix.search_batch_arrays(q, 10)
-    os.environ["VDB_FORCE_EXACT"] = "1"
-    try:
-        b = ix.search_batch_arrays(q, 10)
-        assert ix.last_stats()["exact_queries"] == 9
-    finally:
-        del os.environ["VDB_FORCE_EXACT"]
+    ix.set_tiers(ix.TIERS_FORCE_EXACT)
+    b = ix.search_batch_arrays(q, 10)
+    assert ix.last_stats()["exact_queries"] == 9
+    ix.set_tiers(0)
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     check_against_oracle(vdb, 0, rows, q, 10, ix=ix)

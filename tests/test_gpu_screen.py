@@ -14,22 +14,11 @@ from conftest import load_package
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["f32_rows", "bf16_shadow"])
-def vdb(request):
-    """Every test of this module runs twice: screening from the f32 rows (kernels_fused_bf16.hip) and from the opt-in
-    bf16 shadow copy (kernels_fused_a16.hip, VDB_SHADOW=1 at handle creation).  Expectations are the same."""
+@pytest.fixture(scope="module")
+def vdb():
     v = load_package()
     v.build()
-    if request.param == "bf16_shadow":
-        os.environ["VDB_SHADOW"] = "1"
-    else:
-        os.environ.pop("VDB_SHADOW", None)
-    yield v
-    os.environ.pop("VDB_SHADOW", None)
-
-
-def shadow_on():
-    return os.environ.get("VDB_SHADOW") == "1"
+    return v
 
 
 def make_index(vdb, metric, rows, ids=None):
@@ -86,7 +75,6 @@ def test_screen_tier_vs_oracle_and_f32_tier(vdb, metric, n, d, nq, k, dist):
     a, st, b = both_tiers(ix, q, k)
     assert st["bf16_screen"] == 1 and st["kprime"] == (512 if k > 48 else 256) and st["rows_scanned"] >= n, st
     assert st["pool_overflows"] == 0, st
-    assert st["bf16_shadow"] == (1 if shadow_on() and ((d + 31) // 32) % 2 == 0 else 0), st
     assert same(a, b)
     check_oracle(metric, rows, q, k, a, sorted({0, nq // 2, nq - 1}))
 
@@ -108,7 +96,7 @@ def test_screen_tier_not_used_below_its_minimum_or_above_its_k(vdb):
 
 
 def test_uncertified_queries_go_through_the_f32_tier(vdb):
-    """VDB_FORCE_TIER1 sends every query of the screening tier to the compact f32 re-run: same results."""
+    """VDB_TIERS_FORCE_F32 (vdb_flat_set_tiers) sends every query of the screening tier to the compact f32 re-run: same results."""
     rng = np.random.default_rng(21)
     rows = rng.standard_normal((80000, 72)).astype(np.float32)
     q = rng.standard_normal((37, 72)).astype(np.float32)
@@ -116,12 +104,10 @@ def test_uncertified_queries_go_through_the_f32_tier(vdb):
         ix = make_index(vdb, metric, rows)
         a = ix.search_batch_arrays(q, 10)
         assert ix.last_stats()["f32_tier_queries"] == 0
-        os.environ["VDB_FORCE_TIER1"] = "1"
-        try:
-            b = ix.search_batch_arrays(q, 10)
-            st = ix.last_stats()
-        finally:
-            del os.environ["VDB_FORCE_TIER1"]
+        ix.set_tiers(ix.TIERS_FORCE_F32)
+        b = ix.search_batch_arrays(q, 10)
+        st = ix.last_stats()
+        ix.set_tiers(0)
         assert st["bf16_screen"] == 1 and st["f32_tier_queries"] == 37, st
         assert same(a, b)
         check_oracle(metric, rows, q, 10, b, [0, 36])
@@ -258,65 +244,3 @@ def test_error_semantics_under_the_screen_tier(vdb):
     e.add(10**6, V([float("nan")] + [1.0] * 7))                           # NaN distance: the reference panics (flat_index.rs:62)
     with pytest.raises(vdb.VectorDbError):
         e.search(V([1.0] * 8), 3)
-
-
-def test_shadow_copy_follows_adds_growth_and_toggling(vdb):
-    """vdb_flat_set_shadow on a filled index converts the existing rows; later adds (including a reallocation of the
-    store) maintain the shadow; turning it off frees it.  The results never change."""
-    rng = np.random.default_rng(99)
-    n0, n1, d, nq, k = 70_000, 90_000, 100, 50, 10
-    rows = rng.standard_normal((n0 + n1, d)).astype(np.float32)
-    q = rng.standard_normal((nq, d)).astype(np.float32)
-    os.environ.pop("VDB_SHADOW", None)
-    try:
-        ix = make_index(vdb, 1, rows[:n0])
-        base = ix.search_batch_arrays(q, k)
-        assert ix.last_stats()["bf16_shadow"] == 0
-        ix.set_shadow(True)
-        r = ix.search_batch_arrays(q, k)
-        assert ix.last_stats()["bf16_shadow"] == 1 and ix.last_stats()["bf16_screen"] == 1 and same(r, base)
-        ix.add_bulk(rows[n0:], first_id=n0)                       # grows the store: the shadow is reallocated and extended
-        r2 = ix.search_batch_arrays(q, k)
-        st = ix.last_stats()
-        assert st["bf16_shadow"] == 1 and st["rows_scanned"] >= n0 + n1
-        check_oracle(1, rows, q, k, r2, [0, 17, nq - 1])
-        for j in range(0, 40):                                    # single adds through the host staging path
-            ix.add(10_000_000 + j, vdb.Vector(rows[j] * 1.5))
-        ix.remove(5)
-        r3 = ix.search_batch_arrays(q, k)
-        assert ix.last_stats()["bf16_shadow"] == 1
-        ix.set_shadow(False)
-        r4 = ix.search_batch_arrays(q, k)
-        assert ix.last_stats()["bf16_shadow"] == 0 and same(r3, r4)
-        ix.set_screen(0)
-        assert same(ix.search_batch_arrays(q, k), r4)
-    finally:
-        if shadow_on():
-            os.environ["VDB_SHADOW"] = "1"
-
-
-def test_pipelined_and_unpipelined_filter_pass_agree(vdb):
-    """kernels_fused_bf16p.hip (default) against the unpipelined filter pass of kernels_fused_bf16.hip (VDB_FUSED_PIPE=0 at
-    handle creation): same operands and the same MFMA order per accumulator, so the scores -- and with them the candidate
-    pools, the tier counters and the results -- are identical, including a ragged last tile and tombstones."""
-    rng = np.random.default_rng(4242)
-    n, d, nq, k = 123_457, 200, 77, 10
-    rows = rng.standard_normal((n, d)).astype(np.float32)
-    q = rng.standard_normal((nq, d)).astype(np.float32)
-    res, stats = [], []
-    for pipe in ("1", "0"):
-        os.environ["VDB_FUSED_PIPE"] = pipe
-        try:
-            ix = make_index(vdb, 0, rows)
-        finally:
-            os.environ.pop("VDB_FUSED_PIPE", None)
-        for r in range(0, 3000, 7):
-            ix.remove(r)
-        res.append(ix.search_batch_arrays(q, k))
-        st = ix.last_stats()
-        stats.append({x: st[x] for x in ("bf16_screen", "uncertified", "f32_tier_queries", "rethreshold_queries", "pool_overflows", "exact_queries")})
-    assert stats[0]["bf16_screen"] == 1 and stats[0] == stats[1], stats
-    assert same(res[0], res[1])
-    live = np.ones(n, dtype=np.uint8)
-    live[0:3000:7] = 0
-    check_oracle(0, rows, q, k, res[0], [0, 40, nq - 1], live=live)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Cluster-ordered data (rows stored cluster by cluster, queries next to stored rows): the workload on which the screening
-tier exhausts its re-rank depth.  Times a batch with and without the re-threshold pass (VDB_NO_RETHRESHOLD=1)."""
+tier exhausts its re-rank depth.  Times a batch with and without the re-threshold pass (vdb_flat_set_tiers(VDB_TIERS_NO_RETHRESHOLD))."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,5 @@
 # measurement of the other BASELINE configs on one GPU (documentation; the headline line is plain `python bench.py`)
-run() { echo -n "$1: "; shift; timeout -k 10 280 python bench.py --no-f32-tier --no-shadow "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); r=d['roofline']; s=d['path_stats']; print('QPS', d['value'], 'step_ms', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], r['bound'], r['achieved'], r['unit'], 'recall', d['recall_at_10'], 'screen', s['bf16_screen'], 'f32q', s['f32_tier_queries'], 'exact', s['exact_queries'], 'ovf', s['pool_overflows'], 'S', s['sample_rows'], (d['cpu_baseline'] or {}).get('ids_and_distances_bit_identical'))"; }
+run() { echo -n "$1: "; shift; timeout -k 10 280 python bench.py --no-f32-tier "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); r=d['roofline']; s=d['path_stats']; print('QPS', d['value'], 'step_ms', d['ms_per_step'], 'kernel_ms', r['kernel_ms'], r['bound'], r['achieved'], r['unit'], 'recall', d['recall_at_10'], 'screen', s['bf16_screen'], 'f32q', s['f32_tier_queries'], 'exact', s['exact_queries'], 'ovf', s['pool_overflows'], 'S', s['sample_rows'], (d['cpu_baseline'] or {}).get('ids_and_distances_bit_identical'))"; }
 run "C2 cosine 1Mx768 B256 k10" --steps 60 --warmup 10 --cpu-seconds 6
 run "C2 cosine, gauss data" --data gauss --steps 60 --warmup 10 --cpu-seconds 3
 run "C2 euclid" --metric 0 --steps 60 --warmup 10 --cpu-seconds 3

@@ -1,4 +1,6 @@
 # diagnostic A/B: 3-image LDS-DMA ring with mid-stage barrier (default) vs 2-image variant (VDB_FUSED_DMA2=1); parity first
+# the knobs below exist only in the diagnostics build (make -C vectordb-from-scratch_amd/csrc diag)
+make -C vectordb-from-scratch_amd/csrc -j8 diag >/dev/null && export VDB_LIB=$PWD/vectordb-from-scratch_amd/libvdbflat_diag.so
 VDB_FUSED_DMA2=1 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | tail -3
 for rep in 1 2; do
 for v in "" 1; do echo -n "DMA2=${v:-0} "; env ${v:+VDB_FUSED_DMA2=1} timeout -k 10 120 python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); r=d['roofline']; print('kernel_ms', r['kernel_ms'], 'TF', r['achieved'], 'step_ms', d['ms_per_step'], 'exact', d['path_stats']['exact_queries'])"; done; done

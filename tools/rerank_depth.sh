@@ -1,4 +1,6 @@
 # diagnostic: depth the adaptive re-rank ends at, and the step / re-rank time for several first-round depths
+# the knobs below exist only in the diagnostics build (make -C vectordb-from-scratch_amd/csrc diag)
+make -C vectordb-from-scratch_amd/csrc -j8 diag >/dev/null && export VDB_LIB=$PWD/vectordb-from-scratch_amd/libvdbflat_diag.so
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 VDB_RR_DEPTH=1 timeout -k 10 200 python tools/kernel_time.py 2>&1 | grep "re-rank depth" | tail -2
 for f in ${KP_FIRST_LIST:-32 48}; do

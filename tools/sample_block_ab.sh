@@ -1,4 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# the knobs below exist only in the diagnostics build (make -C vectordb-from-scratch_amd/csrc diag)
+make -C vectordb-from-scratch_amd/csrc -j8 diag >/dev/null && export VDB_LIB=$PWD/vectordb-from-scratch_amd/libvdbflat_diag.so
 for b in 0 1; do
   echo "== VDB_SAMPLE_BLOCK=$b"
   rm -rf gpurun_out/profB

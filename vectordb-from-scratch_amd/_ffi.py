@@ -4,7 +4,9 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvdbflat.so")
+# VDB_LIB names another build of the same ABI (tools/*.sh point it at libvdbflat_diag.so, the -DVDB_DIAG build with the
+# ablation / A-B knobs); the default is the release library, which reads no environment itself
+LIB_PATH = os.environ.get("VDB_LIB") or os.path.join(HERE, "libvdbflat.so")
 
 OK, ERR_DIMENSION_MISMATCH, ERR_INVALID_VECTOR, ERR_NAN, ERR_DEVICE, ERR_INVALID_ARGUMENT, ERR_NOT_FOUND = range(7)
 
@@ -13,12 +15,12 @@ SYMBOLS = [
     "vdb_flat_create", "vdb_flat_destroy", "vdb_flat_add", "vdb_flat_add_bulk", "vdb_flat_add_bulk_device",
     "vdb_flat_load_vector_file", "vdb_flat_remove", "vdb_flat_get_vector", "vdb_flat_len", "vdb_flat_metric", "vdb_flat_dim",
     "vdb_flat_reserve", "vdb_flat_flush", "vdb_flat_search", "vdb_flat_search_batch",
-    "vdb_flat_search_batch_device", "vdb_flat_search_batch_device_begin", "vdb_flat_search_batch_device_finish", "vdb_flat_distances_batch", "vdb_merge_topk_device", "vdb_merge_topk_packed_device", "vdb_flat_set_profile", "vdb_flat_last_stats", "vdb_flat_last_stats_ex", "vdb_flat_set_screen", "vdb_flat_set_shadow", "vdb_last_error",
+    "vdb_flat_search_batch_device", "vdb_flat_search_batch_device_begin", "vdb_flat_search_batch_device_finish", "vdb_flat_distances_batch", "vdb_merge_topk_device", "vdb_merge_topk_packed_device", "vdb_flat_set_profile", "vdb_flat_last_stats", "vdb_flat_last_stats_ex", "vdb_flat_set_screen", "vdb_flat_set_tiers", "vdb_last_error",
     "vdb_abi_version", "vdb_build_arch",
     # include/vdb_hnsw.h
     "vdb_hnsw_create", "vdb_hnsw_destroy", "vdb_hnsw_add", "vdb_hnsw_add_bulk", "vdb_hnsw_remove", "vdb_hnsw_search_batch",
     "vdb_hnsw_len", "vdb_hnsw_metric", "vdb_hnsw_get_vector", "vdb_hnsw_neighbors", "vdb_hnsw_node_level",
-    "vdb_hnsw_entry_point", "vdb_hnsw_stats",
+    "vdb_hnsw_entry_point", "vdb_hnsw_stats", "vdb_hnsw_set_traversal",
 ]
 
 _lib = None
@@ -63,7 +65,7 @@ def lib():
     L.vdb_flat_last_stats.argtypes = [vp, u64p]
     L.vdb_flat_last_stats_ex.argtypes = [vp, u64p, sz]
     L.vdb_flat_set_screen.argtypes = [vp, c.c_int]
-    L.vdb_flat_set_shadow.argtypes = [vp, c.c_int]
+    L.vdb_flat_set_tiers.argtypes = [vp, c.c_uint]
     L.vdb_flat_set_profile.argtypes = [vp, c.c_int]
     L.vdb_last_error.argtypes = [c.c_char_p, sz, szp, szp]
     L.vdb_last_error.restype = None
@@ -84,6 +86,7 @@ def lib():
     L.vdb_hnsw_node_level.restype = c.c_long
     L.vdb_hnsw_entry_point.argtypes = [vp, u64p, szp]
     L.vdb_hnsw_stats.argtypes = [vp, u64p]
+    L.vdb_hnsw_set_traversal.argtypes = [vp, c.c_int, sz]
     L.vdb_abi_version.restype = c.c_int
     L.vdb_build_arch.restype = c.c_char_p
     _lib = L

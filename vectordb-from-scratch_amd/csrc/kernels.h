@@ -70,8 +70,6 @@ struct RowStatsParams {
                              // row, as f32 bits of |x - bf16(x)|^2 (slot 2) and of |x - bf16(x)|^2 / |x|^2 (slot 3)
 };
 void launch_row_stats(const RowStatsParams& p, hipStream_t s);
-// bf16 shadow of rows [row_begin, row_end): v_cvt_pk_bf16_f32 (RNE) of every element of the padded row
-void launch_rows_to_bf16(const float* rows, uint16_t* rows16, uint32_t ld, uint32_t row_begin, uint32_t row_end, hipStream_t s);
 
 // count live rows whose norm is exactly zero (Cosine: distance.rs:51-55)
 void launch_count_zero_live(const float* nd, const uint32_t* livemask, uint32_t n_rows,
@@ -146,15 +144,16 @@ void launch_fused(const FusedParams& p, int nqt, uint32_t n_super, hipStream_t s
 size_t fused_lds_bytes(int nqt);
 uint32_t fused_tile_rows(int nqt);
 uint32_t fused_subpools_per_query(int nqt, uint32_t n_wg);
-// LDS-DMA variant of the headline shape (nqt = 8): same results, stages brought in by global_load_lds
+#ifdef VDB_DIAG
+// 2-image LDS-DMA variant of the headline shape (nqt = 8; diagnostics build: A/B against dma3)
 void launch_fused_dma(const FusedParams& p, uint32_t n_super, hipStream_t s);
+#endif
 // three-image ring, barrier in the middle of a stage (kernels_fused_dma3.hip)
 void launch_fused_dma3(const FusedParams& p, uint32_t n_super, hipStream_t s);
 
 // ---------------------------------------------------------------- bf16 screening tier (kernels_fused_bf16.hip)
 struct FusedBf16Params {
     const float* rows; uint32_t ld; uint32_t n_rows;
-    const uint16_t* rows16;                            // bf16 shadow of `rows` [n_rows][ld] (kernels_fused_a16.hip; used when ld % 64 == 0)
     const uint16_t* qb;                                // [256][ld] bf16 queries of this pass (zero padded)
     const float* alpha; const float* beta;
     const uint32_t* rowmask;                           // NEVER null: the live mask when there is no filter
@@ -168,10 +167,11 @@ struct FusedBf16Params {
     uint32_t n_sample, sample_shift, sample_block; uint64_t* minkeys; uint32_t minkey_stride;   // minkeys[q*minkey_stride + group]
     uint32_t ablate;                                   // diagnostics only (VDB_BF16_ABLATE): 1 skip LDS reads + MFMAs (unpipelined kernel only), 2 skip the row DMA, 4 skip the query DMA, 8 skip the epilogue, 16 (pipelined kernel) thresholds = -inf: nothing passes the filter
 };
-void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s);
+#ifdef VDB_DIAG
+void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s);      // unpipelined filter pass (diagnostics build: A/B against bf16p)
+#endif
 void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s);
 void launch_fused_bf16p(const FusedBf16Params& p, hipStream_t s);     // kernels_fused_bf16p.hip: the filter pass, software-pipelined (default)
-void launch_fused_a16(const FusedBf16Params& p, hipStream_t s);      // the filter pass reading p.rows16 (ld % 64 == 0)
 uint32_t fused_bf16_tile_rows();
 uint32_t fused_bf16_subpools_per_query(uint32_t n_wg);
 uint32_t fused_bf16_sample_groups(uint32_t n_sample);

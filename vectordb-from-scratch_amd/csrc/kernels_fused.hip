@@ -358,7 +358,9 @@ void launch_fused(const FusedParams& p, int nqt, uint32_t n_super, hipStream_t s
     switch (nqt) {
     case 1: hipLaunchKernelGGL((fused_score_filter_kernel<1, 1, 4>), grid, dim3(256), lds, s, p); break;
     case 2: hipLaunchKernelGGL((fused_score_filter_kernel<2, 2, 4>), grid, dim3(256), lds, s, p); break;
-    case 8: hipLaunchKernelGGL((fused_score_filter_kernel<8, 4, 8>), grid, dim3(512), lds, s, p); break;
+#ifdef VDB_DIAG
+    case 8: hipLaunchKernelGGL((fused_score_filter_kernel<8, 4, 8>), grid, dim3(512), lds, s, p); break;   // register-staged 256-query shape (A/B against kernels_fused_dma3.hip)
+#endif
     default: hipLaunchKernelGGL((fused_score_filter_kernel<4, 4, 4>), grid, dim3(256), lds, s, p); break;
     }
 }

@@ -448,9 +448,11 @@ uint32_t fused_bf16_tile_rows() { return TR; }
 uint32_t fused_bf16_subpools_per_query(uint32_t n_wg) { return 4u * n_wg; }
 uint32_t fused_bf16_sample_groups(uint32_t n_sample) { return 4u * ((n_sample + TR - 1) / TR); }
 
+#ifdef VDB_DIAG
 void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s) {
     hipLaunchKernelGGL(fused_bf16_kernel<false>, dim3(p.n_wg), dim3(NT), 0, s, p);
 }
+#endif
 void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s) {
     const uint32_t stiles = (p.n_sample + TR - 1) / TR;
     if (!stiles) return;

@@ -95,8 +95,28 @@ constexpr uint32_t MAX_SELECT = 2048;   // select kernel capacity (kk)
 
 }  // namespace
 
+// Diagnostic knobs: ablation switches, A/B kernel variants, scaled certificates, sample-size overrides.  Several of them
+// VOID the exact-result guarantee, so they exist only in the diagnostics build (-DVDB_DIAG -> libvdbflat_diag.so,
+// `make diag`), where vdb_flat_create reads them from the environment ONCE into the handle.  In the release library
+// this struct is a set of constants and there is no getenv anywhere.
+struct vdb_knobs {
+    double eps_scale = 1.0;               // VDB_EPS_SCALE: scales both certification coefficients (0 = no margin!)
+    uint32_t bf16_ablate = 0;             // VDB_BF16_ABLATE: phases of the screening kernel switched off (wrong results)
+    uint32_t fused_ablate = 0;            // VDB_FUSED_ABLATE: the same for the f32 MFMA kernel
+    uint32_t kt16 = 0, sample16 = 0;      // VDB_KT16 / VDB_SAMPLE16: threshold rank / sample size of the screening tier
+    uint32_t sample = 0;                  // VDB_SAMPLE: sample size of the f32 tier
+    uint32_t kp_first = 0;                // VDB_KP_FIRST: first re-rank round
+    bool rr_depth = false;                // VDB_RR_DEPTH: print the re-rank depth distribution
+    bool sample_block = false;            // VDB_SAMPLE_BLOCK: contiguous-block sampling
+    bool shape4 = false, regstage = false, dma2 = false;   // VDB_FUSED_SHAPE4 / _REGSTAGE / _DMA2: A/B variants of the f32 kernel
+    bool fused_pipe = true;               // VDB_FUSED_PIPE=0: unpipelined screening filter pass
+    bool any = false;                     // some knob differs from its default -> last_stats_ex()[15] = 1
+};
+
 struct vdb_flat_index {
     int metric = 0, device = 0;
+    vdb_knobs kn;
+    uint32_t tiers = 0;                   // vdb_flat_set_tiers: VDB_TIERS_* bits (tier hand-over forced; results identical)
     hipStream_t stream = nullptr;
     int n_cu = 256;
     std::mutex mu;
@@ -116,9 +136,6 @@ struct vdb_flat_index {
     bool live_dirty = false;
 
     // device store
-    uint16_t* d_rows16 = nullptr;         // opt-in bf16 shadow of d_rows [cap_rows][ld] (vdb_flat_set_shadow), else null
-    bool shadow = false;
-    bool fused_pipe = true;               // filter pass: software-pipelined kernel (VDB_FUSED_PIPE=0: the unpipelined one, A/B runs)
     float* d_rows = nullptr; float* d_nd = nullptr; float* d_alpha = nullptr; float* d_beta = nullptr;
     uint64_t* d_row_ids = nullptr; uint32_t* d_live = nullptr; uint32_t* d_scalars = nullptr;  // [0]=nd2max bits [1]=zero count [2],[3]=max bf16 rounding error of a row (abs^2, rel^2)
     uint32_t cap_rows = 0;
@@ -187,12 +204,6 @@ int grow(Index* ix, uint32_t need_rows) {
     HIP_TRY(hipMalloc((void**)&lv, (size_t)cap / 8));
     hipStream_t s = ix->stream;
     uint32_t old = ix->n_uploaded;
-    uint16_t* r16 = nullptr;
-    if (ix->shadow) {
-        HIP_TRY(hipMalloc((void**)&r16, (size_t)cap * ix->ld * 2));
-        if (old && ix->d_rows16) HIP_TRY(hipMemcpyAsync(r16, ix->d_rows16, (size_t)old * ix->ld * 2, hipMemcpyDeviceToDevice, s));
-        HIP_TRY(hipMemsetAsync((char*)r16 + (size_t)old * ix->ld * 2, 0, (size_t)(cap - old) * ix->ld * 2, s));
-    }
     if (old) {
         HIP_TRY(hipMemcpyAsync(rows, ix->d_rows, (size_t)old * row_bytes, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(nd, ix->d_nd, (size_t)old * 4, hipMemcpyDeviceToDevice, s));
@@ -208,8 +219,6 @@ int grow(Index* ix, uint32_t need_rows) {
         (void)hipFree(ix->d_rows); (void)hipFree(ix->d_nd); (void)hipFree(ix->d_alpha);
         (void)hipFree(ix->d_beta); (void)hipFree(ix->d_row_ids); (void)hipFree(ix->d_live);
     }
-    if (ix->d_rows16) (void)hipFree(ix->d_rows16);
-    ix->d_rows16 = r16;
     ix->d_rows = rows; ix->d_nd = nd; ix->d_alpha = al; ix->d_beta = be; ix->d_row_ids = ids; ix->d_live = lv;
     ix->cap_rows = cap;
     ix->live_dirty = true;
@@ -221,8 +230,6 @@ void free_store(Index* ix) {
         (void)hipFree(ix->d_rows); (void)hipFree(ix->d_nd); (void)hipFree(ix->d_alpha);
         (void)hipFree(ix->d_beta); (void)hipFree(ix->d_row_ids); (void)hipFree(ix->d_live);
     }
-    if (ix->d_rows16) (void)hipFree(ix->d_rows16);
-    ix->d_rows16 = nullptr;
     ix->d_rows = ix->d_nd = ix->d_alpha = ix->d_beta = nullptr;
     ix->d_row_ids = nullptr; ix->d_live = nullptr;
     ix->cap_rows = 0;
@@ -327,7 +334,6 @@ int flush(Index* ix) {
         vdb::RowStatsParams rp{ix->d_rows, ix->ld, ix->dim, first, n, ix->metric, ix->d_nd, ix->d_alpha,
                                ix->d_beta, ix->d_scalars};
         vdb::launch_row_stats(rp, s);
-        if (ix->d_rows16) vdb::launch_rows_to_bf16(ix->d_rows, ix->d_rows16, ix->ld, first, n, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(s));   // pending is host memory about to be released
         ix->pending.clear();
@@ -386,7 +392,7 @@ float eps_coef(const Index* ix) {
     else if (ix->metric == vdb::COSINE) c = (2.0 * K + 16.0) * u;
     else c = (2.0 * K + 2.0) * u;
     c *= 1.1;
-    if (const char* e = getenv("VDB_EPS_SCALE")) c *= atof(e);
+    c *= ix->kn.eps_scale;                 // 1.0 outside the diagnostics build
     return (float)c;
 }
 
@@ -395,7 +401,7 @@ float eps_coef(const Index* ix) {
 // known |q - bf16(q)| and the per-index maxima of |d - bf16(d)| (row_stats_kernel).
 float c_acc_bf16(const Index* ix) {
     double c = (double)ix->ld * 2.384185791015625e-07 * 1.05;
-    if (const char* e = getenv("VDB_EPS_SCALE")) c *= atof(e);
+    c *= ix->kn.eps_scale;                 // 1.0 outside the diagnostics build
     return (float)c;
 }
 
@@ -406,17 +412,17 @@ float c_acc_bf16(const Index* ix) {
 // minima come from (nearly) distinct groups.
 constexpr uint32_t BF16_MIN_ROWS = 65536;
 struct Bf16Plan { uint32_t kp = 0, S = 0, shift = 0, kt = 0; };
-Bf16Plan plan_bf16(uint32_t n, size_t k) {
+Bf16Plan plan_bf16(const vdb_flat_index* ix, uint32_t n, size_t k) {
     Bf16Plan pl;
     if (n < BF16_MIN_ROWS || k > 112) return pl;
     const uint32_t want_kt = std::min<uint32_t>(128u, round_up((uint32_t)k + 22u, 32u));
     uint64_t S = std::min<uint64_t>(65536u, std::max<uint64_t>(16384u, pow2_ceil((uint64_t)n / 16u)));
-    if (const char* e = getenv("VDB_SAMPLE16")) S = pow2_ceil(std::max(256, atoi(e)));
+    if (ix->kn.sample16) S = pow2_ceil(std::max(256u, ix->kn.sample16));
     while (S / 256u < want_kt && 2 * S <= n / 2) S *= 2;
     while (S > n) S /= 2;
     // threshold rank: enough for the first re-rank round; the pool (about N/S * kt keys) feeds the deeper rounds
     uint32_t kt = std::min<uint32_t>(want_kt, (uint32_t)(S / 256u));
-    if (const char* e = getenv("VDB_KT16")) kt = std::min<uint32_t>((uint32_t)std::max(1, atoi(e)), (uint32_t)(S / 256u));
+    if (ix->kn.kt16) kt = std::min<uint32_t>(ix->kn.kt16, (uint32_t)(S / 256u));
     if (kt < k + 1 || kt < 16) return pl;
     pl.kp = k > 48 ? 512 : 256;                                  // candidates the select delivers (depth limit of the re-rank)
     pl.S = (uint32_t)S; pl.kt = kt;
@@ -483,7 +489,7 @@ int pass_f32(Index* ix, hipStream_t s, const float* qp, const float* qnorm, floa
     if (!small) {
         uint64_t want = std::max<uint64_t>(n / 256u, (uint64_t)n * kp / 8000u);
         S = (uint32_t)std::min<uint64_t>(65536u, std::max<uint64_t>(2048u, pow2_ceil(want)));
-        if (const char* e = getenv("VDB_SAMPLE")) S = std::min<uint32_t>(n, std::max(64, atoi(e)));
+        if (ix->kn.sample) S = std::min<uint32_t>(n, std::max(64u, ix->kn.sample));
     }
     // candidate pools: one private sub-pool per (query, row range, row part, lane half) of the fused kernel
     const uint32_t capl = 64;
@@ -505,7 +511,7 @@ int pass_f32(Index* ix, hipStream_t s, const float* qp, const float* qnorm, floa
         const uint32_t nb = std::min(SUPER, nq - q0);
         const uint32_t tiles = (nb + 31) / 32;
         // fused-kernel shape: 32 / 64 / 128 queries per workgroup; 2 workgroups per CU in flight
-        static const bool shape8 = getenv("VDB_FUSED_SHAPE4") == nullptr;   // default: ONE 8-wave workgroup per CU, 256 queries share each fetched row tile (VDB_FUSED_SHAPE4 = two 4-wave workgroups of 128 queries)
+        const bool shape8 = !ix->kn.shape4;   // default: ONE 8-wave workgroup per CU, 256 queries share each fetched row tile (diagnostics: two 4-wave workgroups of 128 queries)
         const int nqt = (shape8 && tiles > 4) ? 8 : tiles > 2 ? 4 : (int)tiles;
         const uint32_t n_super = (tiles + nqt - 1) / nqt;          // workgroups along the query axis (1 or 2)
         const float* qp0 = qp + (size_t)q0 * ld;
@@ -529,13 +535,17 @@ int pass_f32(Index* ix, hipStream_t s, const float* qp, const float* qnorm, floa
             vdb::FusedParams fp{ix->d_rows, ld, n, qp, q0, ix->d_alpha, ix->d_beta, d_rowmask ? d_rowmask : ix->d_live,
                                 thr, ix->w_pool.p - (size_t)q0 * n_sub * capl,
                                 ix->w_subcnt.p - (size_t)q0 * n_sub, capl, n_wg,
-                                getenv("VDB_FUSED_ABLATE") ? (uint32_t)atoi(getenv("VDB_FUSED_ABLATE")) : 0u};
+                                ix->kn.fused_ablate};
             const bool prof = ix->profile && !ix->stats[8];       // with the screening tier on, ITS kernel is the one timed
             if (prof) HIP_TRY(hipEventRecord(ix->ev0, s));
-            static const bool use_dma = getenv("VDB_FUSED_REGSTAGE") == nullptr;   // default: LDS-DMA staging (VDB_FUSED_REGSTAGE=1: register-staged variant, same results)
-            static const bool use_dma3 = getenv("VDB_FUSED_DMA2") == nullptr;   // default: 3-image ring with the barrier in mid-stage (VDB_FUSED_DMA2=1: 2-image variant)
-            if (use_dma && use_dma3 && nqt == 8) vdb::launch_fused_dma3(fp, n_super, s);
-            else if (use_dma && nqt == 8) vdb::launch_fused_dma(fp, n_super, s);
+            // 256-query passes: LDS-DMA staging, 3-image ring with the barrier in mid-stage; smaller batches: the
+            // register-staged 128/64/32-query shapes.  (Diagnostics build: the 2-image and register-staged A/B variants.)
+#ifdef VDB_DIAG
+            if (nqt == 8 && ix->kn.regstage) vdb::launch_fused(fp, nqt, n_super, s);
+            else if (nqt == 8 && ix->kn.dma2) vdb::launch_fused_dma(fp, n_super, s);
+            else
+#endif
+            if (nqt == 8) vdb::launch_fused_dma3(fp, n_super, s);
             else vdb::launch_fused(fp, nqt, n_super, s);
             if (prof) {
                 // one super-tile per event pair: wait here so the pair can be reused (profiling mode only)
@@ -597,14 +607,11 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         const uint32_t nb = std::min(SUPER, nq - q0);
         vdb::FusedBf16Params fp{};
         fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w_qb.p + (size_t)q0 * ld;
-        fp.rows16 = ix->d_rows16;
-        const bool a16 = ix->d_rows16 && ld % 64 == 0;         // the shadow kernel fetches two K stages (one 128-byte line) per row request
-        ix->stats[14] = a16;
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
         fp.thr = ix->w_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
-        fp.ablate = getenv("VDB_BF16_ABLATE") ? (uint32_t)atoi(getenv("VDB_BF16_ABLATE")) : 0u;
+        fp.ablate = ix->kn.bf16_ablate;
         fp.n_sample = S; fp.sample_shift = pl.shift;
-        fp.sample_block = getenv("VDB_SAMPLE_BLOCK") ? (n / (S / 256u)) : 0u; fp.minkeys = ix->w_dense.p; fp.minkey_stride = M;
+        fp.sample_block = ix->kn.sample_block ? (n / (S / 256u)) : 0u; fp.minkeys = ix->w_dense.p; fp.minkey_stride = M;
         vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);    // (the sample always reads the f32 rows)
 
         vdb::SelectParams sp{};
@@ -613,9 +620,11 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         vdb::launch_select(sp, nb, s);
 
         if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
-        if (a16) vdb::launch_fused_a16(fp, s);
-        else if (ix->fused_pipe) vdb::launch_fused_bf16p(fp, s);
-        else vdb::launch_fused_bf16(fp, s);
+#ifdef VDB_DIAG
+        if (!ix->kn.fused_pipe) vdb::launch_fused_bf16(fp, s);
+        else
+#endif
+        vdb::launch_fused_bf16p(fp, s);
         if (ix->profile) {
             HIP_TRY(hipEventRecord(ix->ev1, s));
             HIP_TRY(hipEventSynchronize(ix->ev1));
@@ -643,10 +652,9 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         rp.qerr = ix->w_qerr.p + q0; rp.c_acc = c_acc_bf16(ix);
         rp.kp_first = round_up((uint32_t)k + 38u, 16u); rp.kp_step = 32;
         rp.thr_next = d_thr_next ? d_thr_next + q0 : nullptr;
-        // diagnostics: VDB_KP_FIRST overrides the first re-rank round, VDB_RR_DEPTH prints the depth each query ended at
-        static const char* e_first = getenv("VDB_KP_FIRST");
-        if (e_first) rp.kp_first = (uint32_t)std::max(1, atoi(e_first));
-        static const bool dump_depth = getenv("VDB_RR_DEPTH") != nullptr;
+        // diagnostics build: the first re-rank round overridden, the depth each query ended at printed
+        if (ix->kn.kp_first) rp.kp_first = ix->kn.kp_first;
+        const bool dump_depth = ix->kn.rr_depth;
         if (dump_depth) {
             if ((rc = ix->w_depth.ensure(SUPER))) return rc;
             rp.depth = ix->w_depth.p;
@@ -709,12 +717,13 @@ int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo
         const uint32_t nb = std::min(SUPER, nf - q0);
         vdb::FusedBf16Params fp{};
         fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w2_qb.p + (size_t)q0 * ld;
-        fp.rows16 = ix->d_rows16;
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
         fp.thr = ix->w2_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
-        if (ix->d_rows16 && ld % 64 == 0) vdb::launch_fused_a16(fp, s);
-        else if (ix->fused_pipe) vdb::launch_fused_bf16p(fp, s);
-        else vdb::launch_fused_bf16(fp, s);
+#ifdef VDB_DIAG
+        if (!ix->kn.fused_pipe) vdb::launch_fused_bf16(fp, s);
+        else
+#endif
+        vdb::launch_fused_bf16p(fp, s);
         ix->stats[3] += n;
         vdb::SelectParams mp{};
         mp.keys = ix->w_pool.p; mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl; mp.wg_major = 1;
@@ -765,6 +774,7 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
     // events bracket them); the workspace is protected by the handle mutex and the final sync
     hipStream_t s = user_stream ? user_stream : ix->stream;
     memset(ix->stats, 0, sizeof(ix->stats));
+    ix->stats[15] = ix->kn.any ? 1u : 0u;          // diagnostics build with a knob set: the run is NOT covered by the exactness guarantee
     const auto t_entry = std::chrono::steady_clock::now();
     auto since = [&]() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_entry).count(); };
     size_t total_rows = ix->n_live + ix->misfits.size();
@@ -813,7 +823,7 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
     uint32_t* d_ovf = d_cert + nq32;           // [nq]
     // the per-query flags are zeroed by query_prep; the 16-byte status block only needs a memset when the last
     // search left it set (or the buffer is new) -- one launch less at the head of every search
-    const bool flags_by_prep = kp != 0 || (ix->screen && plan_bf16(n, k).kp);
+    const bool flags_by_prep = kp != 0 || (ix->screen && plan_bf16(ix, n, k).kp);
     if (!flags_by_prep) HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, (4 + 3 * (size_t)nq32) * 4, s));
     else if (ix->status_dirty || ix->w_flags.p != ix->status_buf) {
         HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, 16, s));
@@ -832,7 +842,7 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
     // ---- queries: zero-padded copy + exact-order norms
     {
         uint16_t* qb = nullptr;
-        if (ix->screen && plan_bf16(n, k).kp) {
+        if (ix->screen && plan_bf16(ix, n, k).kp) {
             if ((rc = ix->w_qb.ensure((size_t)bp_all * ld))) return rc;
             if ((rc = ix->w_qerr.ensure(bp_all))) return rc;
             qb = ix->w_qb.p;
@@ -842,7 +852,7 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
         vdb::launch_query_prep(qp, s);
     }
 
-    if (kp == 0 && !(ix->screen && plan_bf16(n, k).kp)) {
+    if (kp == 0 && !(ix->screen && plan_bf16(ix, n, k).kp)) {
         // large k: exact scan for every query
         HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -862,7 +872,7 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
 
     // ---- tiers.  Large indexes: the bf16 screening tier first (HBM-bound pass), the queries it cannot certify
     // are re-run as a compact block by the f32 MFMA tier; whatever that cannot certify goes to the exact scan.
-    const Bf16Plan pl16 = ix->screen ? plan_bf16(n, k) : Bf16Plan{};
+    const Bf16Plan pl16 = ix->screen ? plan_bf16(ix, n, k) : Bf16Plan{};
     const uint32_t kp16 = pl16.kp;
     if ((rc = ix->w_cnt.ensure(4 * SUPER + 16))) return rc;
     if (kp16) {
@@ -907,18 +917,20 @@ int search_part2(Index* ix, int* changed) {
     uint32_t status = ix->h_flags[0];
     if (status & vdb::ST_ZERO_QUERY)
         return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
-    const bool force_exact = getenv("VDB_FORCE_EXACT") != nullptr;
+    // vdb_flat_set_tiers: forced hand-over to the slower tiers (tests); every tier returns the same results
+    const bool force_exact = (ix->tiers & VDB_TIERS_FORCE_EXACT) != 0;
+    const bool force_f32 = (ix->tiers & VDB_TIERS_FORCE_F32) != 0;
+    const bool no_rethr = (ix->tiers & VDB_TIERS_NO_RETHRESHOLD) != 0;
     std::vector<uint32_t> todo;
     for (uint32_t q = 0; q < nq32; ++q) {
         bool cert = ix->h_flags[4 + q] != 0, ovf = ix->h_flags[4 + nq32 + q] != 0;
         if (ovf) ++ix->stats[2];
         if (!cert) ++ix->stats[6];
-        if (cert && !ovf && !force_exact && !(kp16 && getenv("VDB_FORCE_TIER1"))) continue;
+        if (cert && !ovf && !force_exact && !(kp16 && force_f32)) continue;
         todo.push_back(q);
     }
     if (changed && !todo.empty()) *changed = 1;
-    static const bool no_rethr = getenv("VDB_NO_RETHRESHOLD") != nullptr;
-    if (kp16 && !todo.empty() && !no_rethr && !force_exact && !getenv("VDB_FORCE_TIER1")) {
+    if (kp16 && !todo.empty() && !no_rethr && !force_exact && !force_f32) {
         // ---- tier 0b: queries with a known score cut get one more HBM-bound pass with that cut as the threshold
         const uint32_t* h_ovf = ix->h_flags + 4 + nq32;
         const float* h_cut = reinterpret_cast<const float*>(ix->h_flags + 4 + 2 * (size_t)nq32);
@@ -1086,9 +1098,19 @@ int vdb_flat_create(int metric, int device, vdb_flat_index** out) {
     ix->metric = metric;
     ix->device = device;
     ix->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char* e = getenv("VDB_SCREEN")) ix->screen = strcmp(e, "f32") != 0 && strcmp(e, "0") != 0;
-    if (const char* e = getenv("VDB_SHADOW")) ix->shadow = strcmp(e, "0") != 0;
-    if (const char* e = getenv("VDB_FUSED_PIPE")) ix->fused_pipe = strcmp(e, "0") != 0;
+#ifdef VDB_DIAG
+    {
+        vdb_knobs& kn = ix->kn;
+        auto num = [&](const char* name, uint32_t& dst) { if (const char* e = getenv(name)) { dst = (uint32_t)std::max(0, atoi(e)); kn.any = true; } };
+        auto flag = [&](const char* name, bool& dst) { if (getenv(name)) { dst = true; kn.any = true; } };
+        if (const char* e = getenv("VDB_EPS_SCALE")) { kn.eps_scale = atof(e); kn.any = true; }
+        num("VDB_BF16_ABLATE", kn.bf16_ablate); num("VDB_FUSED_ABLATE", kn.fused_ablate);
+        num("VDB_KT16", kn.kt16); num("VDB_SAMPLE16", kn.sample16); num("VDB_SAMPLE", kn.sample); num("VDB_KP_FIRST", kn.kp_first);
+        flag("VDB_RR_DEPTH", kn.rr_depth); flag("VDB_SAMPLE_BLOCK", kn.sample_block);
+        flag("VDB_FUSED_SHAPE4", kn.shape4); flag("VDB_FUSED_REGSTAGE", kn.regstage); flag("VDB_FUSED_DMA2", kn.dma2);
+        if (const char* e = getenv("VDB_FUSED_PIPE")) { kn.fused_pipe = strcmp(e, "0") != 0; kn.any = true; }
+    }
+#endif
     if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ix;
         return fail(VDB_ERR_DEVICE, "hipStreamCreate failed");
@@ -1198,7 +1220,6 @@ int vdb_flat_add_bulk_device(vdb_flat_index* ix, const uint64_t* ids, uint64_t f
     vdb::RowStatsParams rp{ix->d_rows, ix->ld, ix->dim, first, first + (uint32_t)n, ix->metric, ix->d_nd,
                            ix->d_alpha, ix->d_beta, ix->d_scalars};
     vdb::launch_row_stats(rp, s);
-    if (ix->d_rows16) vdb::launch_rows_to_bf16(ix->d_rows, ix->d_rows16, ix->ld, first, first + (uint32_t)n, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     ix->n_uploaded = first + (uint32_t)n;
@@ -1516,33 +1537,17 @@ int vdb_flat_last_stats_ex(const vdb_flat_index* ix, uint64_t* out, size_t n) {
     return VDB_OK;
 }
 
+int vdb_flat_set_tiers(vdb_flat_index* ix, unsigned flags) {
+    if (!ix || (flags & ~7u)) return fail(VDB_ERR_INVALID_ARGUMENT, "flags must be a combination of VDB_TIERS_*");
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->tiers = flags;
+    return VDB_OK;
+}
+
 int vdb_flat_set_screen(vdb_flat_index* ix, int mode) {
     if (!ix || mode < 0 || mode > 1) return fail(VDB_ERR_INVALID_ARGUMENT, "mode must be 0 (f32 MFMA tier only) or 1 (bf16 screening tier first)");
     std::lock_guard<std::mutex> g(ix->mu);
     ix->screen = mode;
-    return VDB_OK;
-}
-
-int vdb_flat_set_shadow(vdb_flat_index* ix, int on) {
-    if (!ix || on < 0 || on > 1) return fail(VDB_ERR_INVALID_ARGUMENT, "on must be 0 or 1");
-    std::lock_guard<std::mutex> g(ix->mu);
-    if (ix->ctx.pending) return fail(VDB_ERR_INVALID_ARGUMENT, "a search is pending between begin and finish");
-    HIP_TRY(hipSetDevice(ix->device));
-    int rc;
-    if ((rc = flush(ix))) return rc;
-    if (!on) {
-        if (ix->d_rows16) { HIP_TRY(hipStreamSynchronize(ix->stream)); (void)hipFree(ix->d_rows16); }
-        ix->d_rows16 = nullptr; ix->shadow = false;
-        return VDB_OK;
-    }
-    ix->shadow = true;
-    if (!ix->d_rows16 && ix->cap_rows) {
-        HIP_TRY(hipMalloc((void**)&ix->d_rows16, (size_t)ix->cap_rows * ix->ld * 2));
-        HIP_TRY(hipMemsetAsync(ix->d_rows16, 0, (size_t)ix->cap_rows * ix->ld * 2, ix->stream));
-        vdb::launch_rows_to_bf16(ix->d_rows, ix->d_rows16, ix->ld, 0, ix->n_uploaded, ix->stream);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(ix->stream));
-    }
     return VDB_OK;
 }
 

@@ -130,6 +130,7 @@ struct vdb_hnsw_index {
     size_t out_cap = 0, out_nq_cap = 0;
     uint32_t mirror_ids = 0, stride0 = 0, strideU = 0, max_list = 0;
     uint64_t device_queries = 0, host_redone = 0;
+    bool host_only = false; size_t host_threads = 0;              // vdb_hnsw_set_traversal
     const Node* node(uint64_t id) const { return id < nodes.size() && nodes[id].present ? &nodes[id] : nullptr; }
 };
 
@@ -396,7 +397,7 @@ int vdb_hnsw_remove(vdb_hnsw_index* g, uint64_t id) {             // graph.rs:34
 namespace {
 
 // host traversal (one GPU launch per round for the candidate lists of every query): the path for what the device-resident
-// search does not take (m > 19, ef > 1022, overflowing queries, VDB_HNSW_HOST=1)
+// search does not take (m > 19, ef > 1022, overflowing queries, vdb_hnsw_set_traversal(h, 1, ..))
 int search_host(vdb_hnsw_index* g, const float* queries, size_t nq, size_t dim, size_t k, size_t ef,
                 uint64_t* out_ids, float* out_dists, size_t* out_counts) {
     int rc;
@@ -412,7 +413,7 @@ int search_host(vdb_hnsw_index* g, const float* queries, size_t nq, size_t dim, 
     // threads, each owning a contiguous block of queries; the GPU evaluates the round's pairs in ONE launch.
     unsigned hw = std::thread::hardware_concurrency();
     size_t T = std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)16, std::max<size_t>(nq / 8, 1)});
-    if (const char* e = getenv("VDB_HNSW_THREADS")) T = std::max(1, atoi(e));
+    if (g->host_threads) T = g->host_threads;
     struct Local { std::vector<uint32_t> pq, pr; size_t base = 0; };
     std::vector<Local> loc(T);
     std::vector<uint32_t> pq, pr;
@@ -630,8 +631,7 @@ int vdb_hnsw_search_batch(vdb_hnsw_index* g, const float* queries, size_t nq, si
     if (nq == 0 || !g->has_ep) return VDB_OK;                     // graph.rs:392-395: empty graph -> Ok(vec![])
     if (dim != g->dim) return vdb_internal::set_dim_error(dim, g->dim);   // distance.rs:21-26 on the first evaluation
     const size_t ef_actual = std::max(ef ? ef : g->ef_search, k);
-    static const bool host_only = getenv("VDB_HNSW_HOST") != nullptr;
-    const bool on_device = !host_only && k > 0 && g->nodes.size() < 0xffffffffull &&
+    const bool on_device = !g->host_only && k > 0 && g->nodes.size() < 0xffffffffull &&
                            vdb::hnsw_search_supported((uint32_t)g->dim, (uint32_t)std::min<size_t>(ef_actual, 0xffffffu), (uint32_t)std::min<size_t>(k, 0xffffffu),
                                                       (uint32_t)std::max(g->m_max0, g->m) + 1);
     if (!on_device) return search_host(g, queries, nq, dim, k, ef, out_ids, out_dists, out_counts);
@@ -652,6 +652,14 @@ int vdb_hnsw_search_batch(vdb_hnsw_index* g, const float* queries, size_t nq, si
             out_counts[redo[j]] = c2[j];
         }
     }
+    return VDB_OK;
+}
+
+int vdb_hnsw_set_traversal(vdb_hnsw_index* g, int host_only, size_t host_threads) {
+    if (!g) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->host_only = host_only != 0;
+    g->host_threads = std::min<size_t>(host_threads, 64);
     return VDB_OK;
 }
 

@@ -140,6 +140,12 @@ class GpuHnswIndex(Index):
         has = self._L.vdb_hnsw_entry_point(self._h, ctypes.byref(ep), ctypes.byref(ml))
         return (int(ep.value), int(ml.value)) if has else (None, 0)
 
+    def set_traversal(self, host_only=False, host_threads=0):
+        """Test hook: host_only=True sends every search through the host traversal (results are identical)."""
+        rc = self._L.vdb_hnsw_set_traversal(self._h, int(bool(host_only)), int(host_threads))
+        if rc:
+            _raise(rc)
+
     def stats(self):
         out = (ctypes.c_uint64 * 6)()
         self._L.vdb_hnsw_stats(self._h, out)

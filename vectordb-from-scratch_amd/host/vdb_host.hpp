@@ -134,9 +134,9 @@ public:
         for (size_t i = 0; i < n; ++i) vectors_[first_id + i] = Vector(std::vector<float>(rows + i * dim, rows + (i + 1) * dim));
     }
     vdb_flat_index* handle() const { return h_; }
-    // no reference counterpart: tier selection / the opt-in bf16 shadow copy of the rows (results are identical either way)
+    // no reference counterpart: tier selection (results are identical either way)
     void set_screen(int mode) { check(vdb_flat_set_screen(h_, mode)); }
-    void set_shadow(bool on) { check(vdb_flat_set_shadow(h_, on ? 1 : 0)); }
+    void set_tiers(unsigned flags) { check(vdb_flat_set_tiers(h_, flags)); }
 
 private:
     static void check(int rc) {

@@ -255,11 +255,11 @@ class GpuFlatIndex(Index):
         return [out[int(offsets[b]):int(offsets[b + 1])] for b in range(nq)]
 
     def last_stats(self):
-        out = (ctypes.c_uint64 * 15)()
-        self._L.vdb_flat_last_stats_ex(self._h, out, 15)
+        out = (ctypes.c_uint64 * 16)()
+        self._L.vdb_flat_last_stats_ex(self._h, out, 16)
         keys = ["mfma_queries", "exact_queries", "pool_overflows", "rows_scanned", "sample_rows", "kprime",
                 "uncertified", "fused_kernel_ns", "bf16_screen", "f32_tier_queries", "host_enqueued_ns",
-                "host_flags_ns", "host_total_ns", "rethreshold_queries", "bf16_shadow"]
+                "host_flags_ns", "host_total_ns", "rethreshold_queries", "reserved14", "diag_knobs_active"]
         return dict(zip(keys, [int(v) for v in out]))
 
     def set_screen(self, mode):
@@ -268,10 +268,11 @@ class GpuFlatIndex(Index):
         if rc:
             _raise(rc)
 
-    def set_shadow(self, on=True):
-        """Keep a bf16 shadow copy of the rows (+50 % HBM) for the screening pass to stream instead of the f32 rows.
-        Results are identical; only the bytes the HBM-bound pass reads halve."""
-        rc = self._L.vdb_flat_set_shadow(self._h, int(bool(on)))
+    TIERS_NO_RETHRESHOLD, TIERS_FORCE_F32, TIERS_FORCE_EXACT = 1, 2, 4
+
+    def set_tiers(self, flags):
+        """Test hook: force the hand-over of queries to the slower tiers (VDB_TIERS_*).  Results are identical."""
+        rc = self._L.vdb_flat_set_tiers(self._h, int(flags))
         if rc:
             _raise(rc)
 
