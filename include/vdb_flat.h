@@ -214,6 +214,31 @@ int vdb_flat_set_screen(vdb_flat_index *h, int mode);
 #define VDB_TIERS_FORCE_EXACT 4u    /* hand every query to the exact scan */
 int vdb_flat_set_tiers(vdb_flat_index *h, unsigned flags);
 
+/*
+ * Diagnostics of the screening tier's CERTIFICATE (tests/test_gpu_certificate.py).  The default tier ranks rows by
+ * bf16-MFMA scores and returns exact f32 distances only because a bound on the score error proves that no excluded row
+ * can enter the top k.  These entry points expose the inputs of that proof so that it can be tested
+ * directly instead of end to end.  They do not alter any search.
+ *
+ * vdb_flat_debug_screen_scores: runs query preparation and the PRODUCTION filter kernel over every live row with
+ * thresholds that let everything pass, and returns the ranking score of every (query, row) pair:
+ *   out_scores [nq][rows uploaded] f32 (the NaN pattern 0xffffffff = no key: tombstoned row); nq <= 256;
+ *   raw = 0: the scores the tier ranks by (Dot / Euclid: lower-bound scores, score - g_q * margin_row);
+ *   raw = 1: the plain scores fma(acc, alpha, beta) (under Dot: -acc, the raw MFMA accumulator);
+ *   out_qinfo [nq][4]: exact-order |q|, the bound on |q - bf16(q)|, g_q, 0;
+ *   out_consts [8]: eps_coef, c_acc, kappa, max |d|, max |d - bf16(d)|, max |d - bf16(d)|/|d|, 1 if lower-bound scores, ld.
+ * vdb_flat_debug_rows: number of device rows.  vdb_flat_debug_row_info: out [rows][4] = exact-order |d|, alpha, beta, margin (0 under Cosine).
+ * vdb_flat_debug_cert_probe: out[i] = the production certification test (kernels_aux.hip cert_test) for prepared query
+ *   qi[i] of the last debug_screen_scores call, unexamined-row score bound T[i] and k-th exact distance ek[i].
+ *   Soundness means: probe(T = score of row r, ek = exact distance of row r) is 0 for EVERY pair.
+ */
+int vdb_flat_debug_screen_scores(vdb_flat_index *h, const float *queries, size_t nq, size_t dim, int raw,
+                                 float *out_scores, float *out_qinfo, double *out_consts);
+size_t vdb_flat_debug_rows(const vdb_flat_index *h); /* device rows incl. tombstoned ones (row i = i-th row ever added since the last reset) */
+int vdb_flat_debug_row_info(vdb_flat_index *h, float *out, size_t n_rows);
+int vdb_flat_debug_cert_probe(vdb_flat_index *h, const uint32_t *qi, const float *T, const float *ek, size_t n,
+                              uint32_t *out);
+
 /* Thread-local message of the last failing call on this thread, plus the
  * DimensionMismatch pair (error.rs:12-13).  Any pointer may be NULL. */
 void vdb_last_error(char *buf, size_t cap, size_t *expected, size_t *actual);

@@ -67,7 +67,13 @@ struct RowStatsParams {
     float* alpha;     // score = fma(dot, alpha, beta)
     float* beta;
     uint32_t* nd2max_bits;   // atomicMax of the f32 bits of fold(x*x); [2] / [3]: max of the bf16 rounding error of a
-                             // row, as f32 bits of |x - bf16(x)|^2 (slot 2) and of |x - bf16(x)|^2 / |x|^2 (slot 3)
+                             // row, as f32 bits of |x - bf16(x)|^2 (slot 2) and of |x - bf16(x)|^2 / |x|^2 (slot 3);
+                             // [4]: atomicMin of ~bits of the smallest positive finite margin (stored complemented so that 0 = none yet)
+    // Screening-tier certificate, LOCAL form (Dot / Euclid; null under Cosine, whose relative row error is bounded by
+    // 2^-9 whatever the data): margin[row] = max(m_e |x - bf16(x)| + m_n |x|, m_b |x|), rounded up, so that
+    // g_q * margin[row] >= the whole row-dependent part of the score error for a query with g_q = |q| + kappa |q - bf16(q)|
+    // (QueryPrepParams::kappa, m_b = B/kappa); beta_shrink: Euclid's beta = |x|^2 (1 - beta_shrink), rounded down.
+    float* margin; float m_e, m_n, m_b, beta_shrink;
 };
 void launch_row_stats(const RowStatsParams& p, hipStream_t s);
 
@@ -89,6 +95,7 @@ struct QueryPrepParams {
     uint32_t* status;
     uint16_t* qb;                                      // may be null: [nq_pad][ld] bf16 (RNE) copy for the screening tier
     float* qerr;                                       // with qb: |q - bf16(q)| per query (upper bound)
+    float* qg; float kappa;                            // with qb (may be null): g_q = |q| + kappa |q - bf16(q)|, rounded up (RowStatsParams::margin)
     uint32_t* clear_a; uint32_t* clear_b;              // may be null: per-query flag words this kernel zeroes (cert, overflow)
 };
 void launch_query_prep(const QueryPrepParams& p, hipStream_t s);
@@ -117,6 +124,8 @@ struct SelectParams {
     uint64_t* out_keys; uint32_t out_stride;           // sorted ascending, padded with EMPTY_KEY
     uint32_t* out_cnt;
     float* out_thr;                                    // may be null: score of the kk-th key, +inf if fewer
+    const float* shift_g; const uint32_t* shift_m_bits; // may be null: out_thr[q] -= shift_g[q] * f32(*shift_m_bits)  (plain-score
+                                                       // sample threshold -> lower-bound units, see launch_sample_bf16)
     uint32_t* ovf;                                     // may be null: set when counts[q] > cap
     uint32_t* summary;                                 // may be null: OR-ed with 2 whenever an overflow flag is set
     uint32_t flag_truncation;                          // 1: more valid keys than kk also sets ovf[q] (the caller needs ALL of them)
@@ -156,6 +165,10 @@ struct FusedBf16Params {
     const float* rows; uint32_t ld; uint32_t n_rows;
     const uint16_t* qb;                                // [256][ld] bf16 queries of this pass (zero padded)
     const float* alpha; const float* beta;
+    // non-null (Dot / Euclid): the kernels rank by the LOWER-BOUND score  fma(-qg[q], margin[row], fma(dot, alpha, beta)),
+    // i.e. the score minus everything the bf16 rounding, the MFMA accumulation and the oracle's own f32 fold can
+    // contribute for THIS row and query -- the certificate then needs no per-index maxima (kernels_aux.hip cert_test)
+    const float* margin; const float* qg;
     const uint32_t* rowmask;                           // NEVER null: the live mask when there is no filter
     // filter mode: keys with score <= thr[q] go to the private sub-pool
     //   sub = ((q*n_wg + range)*2 + row half)*2 + lane half ; keys at pool[sub*capl ..], count at pool_cnt[sub]
@@ -211,6 +224,9 @@ struct RerankParams {
     const float* qerr; float c_acc;                    // bf16 screening tier (qerr != null): |q - bf16(q)| per query and the
                                                        // MFMA accumulation coefficient; the row-side error maxima are
                                                        // nd2max_bits[2] and [3]
+    uint32_t lb_scores;                                // 1 (with qerr; Dot / Euclid): candidate scores and thresholds are the
+                                                       // LOWER-BOUND scores of FusedBf16Params::margin -- every row-dependent
+                                                       // error term is already inside them
     uint32_t lds_row_stride, lds_chunk;                // filled by launch_rerank
 };
 void launch_rerank(const RerankParams& p, uint32_t nq, hipStream_t s);
@@ -286,6 +302,14 @@ struct PairEvalParams {
     float* out;
 };
 void launch_pair_eval(const PairEvalParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------- certificate diagnostics (vdb_flat_debug_*)
+// dense[q*n_rows + row] = score bits of every key the filter pass wrote for query q (wg-major pools of the bf16 tier)
+void launch_pool_to_dense(const uint64_t* pool, const uint32_t* pool_cnt, uint32_t n_sub, uint32_t capl, uint32_t nq,
+                          uint32_t n_rows, float* dense, hipStream_t s);
+// out[i] = cert_test(p, qi[i], T[i], ek[i]) -- the PRODUCTION certification function of rerank_kernel, probed directly
+void launch_cert_probe(const RerankParams& p, const uint32_t* qi, const float* T, const float* ek, uint32_t n, uint32_t* out,
+                       hipStream_t s);
 
 // *code = VDB_PENDING_HOST (100) when the status block of a search (flags[0] status bits, flags[1] summary of
 // uncertified / overflowed queries) is non-zero, else 0

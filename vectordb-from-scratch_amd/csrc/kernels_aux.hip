@@ -117,28 +117,56 @@ __global__ __launch_bounds__(256) void row_stats_kernel(RowStatsParams p) {
         nd2 = fold_sq(x, p.dim);
         float nd = __builtin_sqrtf(nd2);
         p.nd[row] = nd;
+        // bf16 rounding error of the row (screening-tier certification): |x - bf16(x)|^2 and |x|^2 accumulated in f64 (each
+        // term is exact in f64, the sum is good to 2^-53 dim) and rounded UP when stored as f32 -- an f32 sum would be off by
+        // up to dim 2^-24 relative, more than any fixed slack once dim reaches the thousands
+        double e2d = 0.0, n2d = 0.0;
+        for (uint32_t i = 0; i < p.dim; ++i) {
+            const double xv = (double)x[i], e = xv - (double)bf16_round(x[i]);
+            e2d += e * e;
+            n2d += xv * xv;
+        }
+        auto up = [](double v) { float f = (float)v; return ((double)f < v) ? __uint_as_float(__float_as_uint(f) + 1u) : f; };   // v >= 0
+        e2 = up(e2d * 1.0000001);
+        rel2 = n2d > 0.0 ? up(e2d / n2d * 1.0000001) : 0.0f;
+        if (!(e2 == e2)) e2 = 0.0f;                    // NaN / inf rows are caught by the NaN status, not by this bound
+        if (!(rel2 == rel2)) rel2 = 0.0f;
         float a, b;
-        if (p.metric == EUCLID) { a = -2.0f; b = nd2; }
+        if (p.metric == EUCLID) {
+            a = -2.0f;
+            // beta = |x|^2 minus the row's own share of the f32-fold error budget, rounded DOWN (a smaller score is safe)
+            const double bd = (double)nd2 * (1.0 - (double)p.beta_shrink);
+            b = (float)bd;
+            if ((double)b > bd) b = __uint_as_float(__float_as_uint(b) - 1u);
+            if (!p.margin) b = nd2;
+        }
         else if (p.metric == COSINE) { a = -__fdiv_rn(1.0f, nd); b = 0.0f; }
         else { a = -1.0f; b = 0.0f; }
         p.alpha[row] = a;
         p.beta[row] = b;
-        // bf16 rounding error of the row (screening-tier certification): |x - bf16(x)|^2, rounded up a little
-        for (uint32_t i = 0; i < p.dim; ++i) { float e = x[i] - bf16_round(x[i]); e2 += e * e; }
-        e2 *= 1.0001f;
-        rel2 = nd2 > 0.0f ? e2 / nd2 * 1.0001f : 0.0f;
-        if (!(e2 == e2)) e2 = 0.0f;                    // NaN / inf rows are caught by the NaN status, not by this bound
-        if (!(rel2 == rel2)) rel2 = 0.0f;
+        if (p.margin) {
+            // true norms in f64 (the f32 fold `nd` may be off by dim 2^-24 relative)
+            const double ed = sqrt(e2d), ndd = sqrt(n2d);
+            const double m1 = (double)p.m_e * ed + (double)p.m_n * ndd, m2 = (double)p.m_b * ndd;
+            const double m = (m1 > m2 ? m1 : m2) * 1.000001;
+            float mf = (float)m;                       // inf for a row whose norm overflows: its lower-bound score is -inf, it is always a candidate
+            if ((double)mf < m) mf = __uint_as_float(__float_as_uint(mf) + 1u);
+            p.margin[row] = mf;                        // NaN rows: NaN margin -> NaN score -> kept by the filter -> NaN distance reported
+            if (mf > 0.0f && mf < __uint_as_float(0x7f800000u)) atomicMax(p.nd2max_bits + 4, ~__float_as_uint(mf));   // smallest positive margin
+        }
     }
     // wave max of the (non-negative or NaN) bit patterns, one atomic per wave
     uint32_t bits = __float_as_uint(nd2) & 0x7fffffffu, be = __float_as_uint(e2), br = __float_as_uint(rel2);
+    uint32_t bmin = (row < p.row_end && nd2 > 0.0f) ? __float_as_uint(nd2) : 0xffffffffu;
     for (int o = 32; o > 0; o >>= 1) {
         uint32_t t = __shfl_xor(bits, o); bits = t > bits ? t : bits;
+        t = __shfl_xor(bmin, o); bmin = t < bmin ? t : bmin;
         t = __shfl_xor(be, o); be = t > be ? t : be;
         t = __shfl_xor(br, o); br = t > br ? t : br;
     }
     if ((threadIdx.x & 63) == 0) {
         if (bits) atomicMax(p.nd2max_bits, bits);
+        if (bmin != 0xffffffffu) atomicMax(p.nd2max_bits + 5, ~bmin);      // smallest positive fold(x*x), stored complemented (0 = none yet)
         if (be) atomicMax(p.nd2max_bits + 2, be);
         if (br) atomicMax(p.nd2max_bits + 3, br);
     }
@@ -226,7 +254,9 @@ __global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepParams p) {
         __syncthreads();
         if (threadIdx.x == 0) {
             float t = (sE[0] + sE[1]) + (sE[2] + sE[3]);
-            t = __builtin_sqrtf(t) * 1.0001f;
+            // f32 partial sums of non-negative terms: relative error below (ld/256 + 8) 2^-24 per thread chain and tree; the
+            // slack grows with the row length so that it holds up to the largest supported dimension
+            t = __builtin_sqrtf(t) * (1.0001f + (float)p.ld * 1.0e-7f);
             p.qerr[q] = (t == t) ? t : 0.0f;
         }
     }
@@ -238,6 +268,11 @@ __global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepParams p) {
             if (p.metric == COSINE && n == 0.0f) atomicOr(p.status, ST_ZERO_QUERY);
         }
         p.qnorm[q] = n;
+        if (p.qb && p.qg) {
+            // g_q = (|q| + kappa |q - bf16(q)|), rounded up; |q| from the f32 fold may be low by ld 2^-24 relative
+            const float g = (n * (1.00001f + (float)p.ld * 1.2e-7f) + p.kappa * p.qerr[q]) * 1.00001f;
+            p.qg[q] = (q < p.nq) ? g : 0.0f;
+        }
         if (q >= p.nq) p.thr[q] = __uint_as_float(0xff800000u);   // -inf
         if (q < p.nq && p.clear_a) { p.clear_a[q] = 0u; p.clear_b[q] = 0u; }
     }
@@ -521,8 +556,14 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
     if (tid == 0) {
         p.out_cnt[q] = kk;
         if (p.out_last) p.out_last[q] = sOut[kk - 1];
-        if (p.out_thr)
-            p.out_thr[q] = (kk == p.kk) ? ordered_to_f32((uint32_t)(sOut[kk - 1] >> 32)) : __uint_as_float(0x7f800000u);
+        if (p.out_thr) {
+            float t = (kk == p.kk) ? ordered_to_f32((uint32_t)(sOut[kk - 1] >> 32)) : __uint_as_float(0x7f800000u);
+            if (p.shift_g) {
+                const uint32_t mb = *p.shift_m_bits;
+                if (mb) t = fmaf(-p.shift_g[q], __uint_as_float(~mb), t);
+            }
+            p.out_thr[q] = t;
+        }
     }
 }
 void launch_select(const SelectParams& p, uint32_t nq, hipStream_t s) {
@@ -545,11 +586,36 @@ void launch_select(const SelectParams& p, uint32_t nq, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // The certification test: every row not re-ranked has ranking score >= T; is the k-th exact distance ek below the
 // lower bound that T implies for such a row's exact distance?  (DESIGN.md "certified top-k")
+// UNDERFLOW (found by tests/test_gpu_certificate.py "subnormal"): every bound below takes f32 norms and sums as accurate
+// to a few K 2^-24 RELATIVE.  That fails when the squares underflow f32 (|x| below ~1e-19: fold(x*x) loses its low terms
+// or all of them), so
+//   * a query whose exact-order norm is below 2^-40 is never certified by an MFMA tier (it ends in the exact scan);
+//   * under Cosine an index holding a live-or-dead row with 0 < |d| < 2^-40 certifies nothing (same consequence);
+//   * every test gives away an ABSOLUTE floor of K 2^-140 in product units for the f32 operations that underflowed
+//     along the way (each loses less than 2^-149; the MFMA accumulators themselves keep denormals -- measured).
+constexpr double CERT_TINY_NORM = 9.094947017729282e-13;        // 2^-40
+__device__ __forceinline__ double cert_floor(const RerankParams& p) { return (double)p.ld * 7.174648137343064e-43; }   // ld 2^-140
 __device__ __forceinline__ bool cert_test(const RerankParams& p, uint32_t q, float T, double ek, double qn) {
     const double eps = (double)p.eps_coef;
     const double ndmax = sqrt((double)__uint_as_float(p.nd2max_bits[0]));
+    const double fl = cert_floor(p);
+    if (!(qn >= CERT_TINY_NORM)) return false;
+    if (p.metric == COSINE) {
+        const uint32_t mb = p.nd2max_bits[5];
+        if (mb && !(__uint_as_float(~mb) >= (float)(CERT_TINY_NORM * CERT_TINY_NORM))) return false;
+    }
+    if (p.qerr && p.lb_scores) {
+        // bf16 screening tier, Dot / Euclid: T is a LOWER-BOUND score (FusedBf16Params::margin) -- the bf16 rounding of
+        // row and query, the MFMA accumulation and the row's share of the f32-fold budget were subtracted per row in the
+        // kernel, so only the query's own terms are left here and no per-index maximum enters: one huge-norm row
+        // loosens nobody's certificate but its own.  (1 - 2^-22): the f32 rounding of the margin fma.
+        const double Tl = (double)T - fabs((double)T) * 2.4e-7;
+        if (p.metric == DOT) return ek < Tl - fl;
+        return ek * ek < Tl + qn * qn - eps * (qn * qn + ek * ek) - 4.0 * fl;
+    }
     if (p.qerr) {
-        // bf16 screening tier.  With e_q = q - bf16(q) (known) and e_d = d - bf16(d):
+        // bf16 screening tier (Cosine: the relative rounding error of a row is bounded by 2^-9 whatever its norm, so the
+        // per-index maximum of it is a local quantity already).  With e_q = q - bf16(q) (known) and e_d = d - bf16(d):
         //   dot(q,d) - dot(bf16 q, bf16 d) = e_q.d + bf16(q).e_d ,  |.| <= |e_q||d| + |bf16 q||e_d|   (Cauchy-Schwarz)
         // plus the f32 accumulation inside the MFMAs (c_acc |q||d|).  |bf16 q| <= 1.004 |q|; 1 % covers the f32
         // evaluation of the norms.  eps is the f32 tier's coefficient (oracle fold + fma chain).
@@ -559,20 +625,20 @@ __device__ __forceinline__ bool cert_test(const RerankParams& p, uint32_t q, flo
         const double cacc = (double)p.c_acc;
         if (p.metric == DOT) {
             const double E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
-            return ek < (double)T - E - eps * qn * ndmax;
+            return ek < (double)T - E - eps * qn * ndmax - fl;
         } else if (p.metric == COSINE) {
             const double Ec = 1.01 * (eq / qn + 1.004 * rmax) + cacc;
-            return ek < 1.0 + (double)T / qn - Ec - eps;
+            return ek < 1.0 + (double)T / qn - Ec - eps - fl / (qn * CERT_TINY_NORM);
         } else {
             const double E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
             const double s = qn + ndmax;
-            return ek * ek < (double)T + qn * qn - 2.0 * E - eps * (s * s + ek * ek);
+            return ek * ek < (double)T + qn * qn - 2.0 * E - eps * (s * s + ek * ek) - 4.0 * fl;
         }
     }
-    if (p.metric == DOT) return ek < (double)T - eps * qn * ndmax;
-    if (p.metric == COSINE) return ek < 1.0 + (double)T / qn - eps;
+    if (p.metric == DOT) return ek < (double)T - eps * qn * ndmax - fl;
+    if (p.metric == COSINE) return ek < 1.0 + (double)T / qn - eps - fl / (qn * CERT_TINY_NORM);
     const double s = qn + ndmax;
-    return ek * ek < (double)T + qn * qn - eps * (s * s + ek * ek);
+    return ek * ek < (double)T + qn * qn - eps * (s * s + ek * ek) - 4.0 * fl;
 }
 
 // The inverse of cert_test: the smallest score T* such that cert_test(T) holds for every T > T*.  Every row whose
@@ -590,14 +656,55 @@ __device__ __forceinline__ float score_cut(const RerankParams& p, uint32_t q, do
         E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
         Ec = 1.01 * (eq / qn + 1.004 * rmax) + cacc;
     }
+    const double fl = cert_floor(p);
+    if (!(qn >= CERT_TINY_NORM)) return __uint_as_float(0x7fc00000u);          // not certifiable on an MFMA tier: no cut
+    if (p.metric == COSINE) {
+        const uint32_t mb = p.nd2max_bits[5];
+        if (mb && !(__uint_as_float(~mb) >= (float)(CERT_TINY_NORM * CERT_TINY_NORM))) return __uint_as_float(0x7fc00000u);
+    }
     double t;
-    if (p.metric == DOT) t = ek + E + eps * qn * ndmax;
-    else if (p.metric == COSINE) t = (ek - 1.0 + Ec + eps) * qn;
-    else { const double s = qn + ndmax; t = ek * ek - qn * qn + 2.0 * E + eps * (s * s + ek * ek); }
+    if (p.qerr && p.lb_scores) {
+        t = p.metric == DOT ? ek + fl : ek * ek - qn * qn + eps * (qn * qn + ek * ek) + 4.0 * fl;
+        t += fabs(t) * 2.4e-7;
+    }
+    else if (p.metric == DOT) t = ek + E + eps * qn * ndmax + fl;
+    else if (p.metric == COSINE) t = (ek - 1.0 + Ec + eps + fl / (qn * CERT_TINY_NORM)) * qn;
+    else { const double s = qn + ndmax; t = ek * ek - qn * qn + 2.0 * E + eps * (s * s + ek * ek) + 4.0 * fl; }
     t += fabs(t) * 1e-6 + 1e-30;                                // slack: looser is safe
     float f = (float)t;
     if ((double)f < t) f = __uint_as_float(__float_as_uint(f) + (f >= 0.0f ? 1u : (uint32_t)-1));   // round towards +inf
     return f;
+}
+
+// ---- certificate diagnostics (tests/test_gpu_certificate.py through vdb_flat_debug_*)
+__global__ __launch_bounds__(256) void pool_to_dense_kernel(const uint64_t* pool, const uint32_t* pool_cnt, uint32_t n_sub,
+                                                            uint32_t capl, uint32_t n_rows, float* dense) {
+    const uint32_t q = blockIdx.y, i = blockIdx.x;                 // sub-pool i = wg*4 + r of query q
+    uint32_t c = pool_cnt[(size_t)q * n_sub + i];
+    if (c > capl) c = capl;
+    const uint64_t* src = pool + (((size_t)(i >> 2) * 256u + q) * 4u + (i & 3u)) * capl;
+    for (uint32_t j = threadIdx.x; j < c; j += blockDim.x) {
+        const uint64_t raw = src[j];
+        const uint32_t row = (uint32_t)raw;
+        if (row < n_rows) dense[(size_t)q * n_rows + row] = __uint_as_float((uint32_t)(raw >> 32));
+    }
+}
+void launch_pool_to_dense(const uint64_t* pool, const uint32_t* pool_cnt, uint32_t n_sub, uint32_t capl, uint32_t nq,
+                          uint32_t n_rows, float* dense, hipStream_t s) {
+    if (!nq || !n_sub) return;
+    hipLaunchKernelGGL(pool_to_dense_kernel, dim3(n_sub, nq), dim3(256), 0, s, pool, pool_cnt, n_sub, capl, n_rows, dense);
+}
+__global__ __launch_bounds__(256) void cert_probe_kernel(RerankParams p, const uint32_t* qi, const float* T, const float* ek,
+                                                         uint32_t n, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t q = qi[i];
+    out[i] = cert_test(p, q, T[i], (double)ek[i], (double)p.qnorm[q]) ? 1u : 0u;
+}
+void launch_cert_probe(const RerankParams& p, const uint32_t* qi, const float* T, const float* ek, uint32_t n, uint32_t* out,
+                       hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(cert_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, qi, T, ek, n, out);
 }
 
 typedef __attribute__((address_space(3))) void* rr_lds_t;

@@ -63,7 +63,9 @@ __device__ __forceinline__ bf16x8 cvt8(const float4& lo, const float4& hi) {
 }
 }  // namespace
 
-template <bool SAMPLE>
+// MARGIN: lower-bound scores for Dot / Euclid, exactly as in kernels_fused_bf16p.hip (same two fmas per element, so the
+// sample's group minima and the filter pass agree bit for bit).
+template <bool SAMPLE, bool MARGIN>
 __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
     // three DISTINCT LDS objects, each access names its image at compile time (see kernels_fused_dma3.hip)
     __shared__ __attribute__((aligned(16))) char sImg0[STAGE_BYTES];
@@ -71,13 +73,15 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
     __shared__ __attribute__((aligned(16))) char sImg2[STAGE_BYTES];
     // per-row constants of a tile (alpha, beta, the row's eligibility-mask word), double buffered by tile parity;
     // filled by LDS-DMA as well, so that no wave ever holds a pending ordinary load inside the stage loop
-    __shared__ __attribute__((aligned(16))) float sAlpha[2 * TR];
-    __shared__ __attribute__((aligned(16))) float sBeta[2 * TR];
-    __shared__ __attribute__((aligned(16))) uint32_t sMaskW[2 * TR];
+    __shared__ __attribute__((aligned(16))) float sAlpha[SAMPLE ? TR : 2 * TR];            // (sample mode: one tile per workgroup, parity 0 only)
+    __shared__ __attribute__((aligned(16))) float sBeta[SAMPLE ? TR : 2 * TR];
+    __shared__ __attribute__((aligned(16))) uint32_t sMaskW[SAMPLE ? TR : 2 * TR];
     // sample mode: the device rows of the (single) tile's scattered sample rows live here instead of in four 64-bit address
     // registers per lane (with those the sample instance spilled in its last stages, and every scratch reload is a
     // vmcnt(0) -- a drain of the DMA pipeline); each lane reads back only what it wrote
     __shared__ uint32_t sRow[SAMPLE ? 32 * 64 : 1];
+    __shared__ __attribute__((aligned(16))) float sMarg[MARGIN ? (SAMPLE ? TR : 2 * TR) : 4];
+    __shared__ float sG[MARGIN ? TQ : 1];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -236,8 +240,12 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
             VDB_DMA4(p.rowmask + (row >> 5), sMaskW + par * TR + cr);
         } else {
             VDB_DMA4(p.beta + row, sBeta + par * TR + cr);
+            if (MARGIN) VDB_DMA4(p.margin + row, sMarg + par * TR + cr);
         }
     };
+    if (MARGIN) {
+        if (tid < TQ) { float g = p.qg[tid]; asm volatile("" : "+v"(g)); sG[tid] = g; }
+    }
 
     f32x16 acc[MT][QT];
 #pragma unroll
@@ -351,6 +359,9 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
             float best_a = __uint_as_float(0x7f800000u), best_b = best_a;   // sample mode: running group minima
             const float* al = sAlpha + par * TR + wr * 128 + 4 * h;
             const float* be = sBeta + par * TR + wr * 128 + 4 * h;
+            const float* mg = sMarg + (MARGIN ? par * TR + wr * 128 + 4 * h : 0);
+            float ng_a = 0.f, ng_b = 0.f;
+            if (MARGIN) { ng_a = -sG[q_a]; ng_b = -sG[q_b]; }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const uint32_t vbits = (uint32_t)(val[i >> 1] >> (32 * (i & 1) + 4 * h));
@@ -360,10 +371,15 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
                     const float4 a4 = *reinterpret_cast<const float4*>(al + i * 32 + 8 * j);
                     const float4 b4 = *reinterpret_cast<const float4*>(be + i * 32 + 8 * j);
                     // scores of 4 rows x 2 queries
-                    const float sa0 = fmaf(acc[i][0][4 * j + 0], a4.x, b4.x), sa1 = fmaf(acc[i][0][4 * j + 1], a4.y, b4.y);
-                    const float sa2 = fmaf(acc[i][0][4 * j + 2], a4.z, b4.z), sa3 = fmaf(acc[i][0][4 * j + 3], a4.w, b4.w);
-                    const float sb0 = fmaf(acc[i][1][4 * j + 0], a4.x, b4.x), sb1 = fmaf(acc[i][1][4 * j + 1], a4.y, b4.y);
-                    const float sb2 = fmaf(acc[i][1][4 * j + 2], a4.z, b4.z), sb3 = fmaf(acc[i][1][4 * j + 3], a4.w, b4.w);
+                    float sa0 = fmaf(acc[i][0][4 * j + 0], a4.x, b4.x), sa1 = fmaf(acc[i][0][4 * j + 1], a4.y, b4.y);
+                    float sa2 = fmaf(acc[i][0][4 * j + 2], a4.z, b4.z), sa3 = fmaf(acc[i][0][4 * j + 3], a4.w, b4.w);
+                    float sb0 = fmaf(acc[i][1][4 * j + 0], a4.x, b4.x), sb1 = fmaf(acc[i][1][4 * j + 1], a4.y, b4.y);
+                    float sb2 = fmaf(acc[i][1][4 * j + 2], a4.z, b4.z), sb3 = fmaf(acc[i][1][4 * j + 3], a4.w, b4.w);
+                    if (MARGIN) {
+                        const float4 m4 = *reinterpret_cast<const float4*>(mg + i * 32 + 8 * j);
+                        sa0 = fmaf(ng_a, m4.x, sa0); sa1 = fmaf(ng_a, m4.y, sa1); sa2 = fmaf(ng_a, m4.z, sa2); sa3 = fmaf(ng_a, m4.w, sa3);
+                        sb0 = fmaf(ng_b, m4.x, sb0); sb1 = fmaf(ng_b, m4.y, sb1); sb2 = fmaf(ng_b, m4.z, sb2); sb3 = fmaf(ng_b, m4.w, sb3);
+                    }
                     const uint32_t rt0 = rowb + 8 * j;                  // tile-row of element 0
                     if (SAMPLE) {
                         // smallest score of the lane's eligible rows (v_min_f32 skips a NaN score: such a row is no witness
@@ -450,14 +466,19 @@ uint32_t fused_bf16_sample_groups(uint32_t n_sample) { return 4u * ((n_sample + 
 
 #ifdef VDB_DIAG
 void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s) {
-    hipLaunchKernelGGL(fused_bf16_kernel<false>, dim3(p.n_wg), dim3(NT), 0, s, p);
+    if (p.margin) hipLaunchKernelGGL((fused_bf16_kernel<false, true>), dim3(p.n_wg), dim3(NT), 0, s, p);
+    else hipLaunchKernelGGL((fused_bf16_kernel<false, false>), dim3(p.n_wg), dim3(NT), 0, s, p);
 }
 #endif
 void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s) {
     const uint32_t stiles = (p.n_sample + TR - 1) / TR;
     if (!stiles) return;
     (void)n_cu;
-    hipLaunchKernelGGL(fused_bf16_kernel<true>, dim3(stiles), dim3(NT), 0, s, p);
+    // The sample ALWAYS ranks by the plain score, also when the filter pass ranks by lower-bound scores (p.margin): its
+    // instance with the margin fma spills (scratch reloads drain the DMA pipeline), and it does not need it -- any
+    // threshold is valid, and the select shifts this one by g_q * (smallest row margin of the index), after which every
+    // sample row that met the plain threshold meets the shifted one in lower-bound units (SelectParams::shift_g).
+    hipLaunchKernelGGL((fused_bf16_kernel<true, false>), dim3(stiles), dim3(NT), 0, s, p);
 }
 
 }  // namespace vdb

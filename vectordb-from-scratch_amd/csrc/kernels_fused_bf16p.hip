@@ -47,7 +47,10 @@ __device__ __forceinline__ bf16x8 cvt8(const float4& lo, const float4& hi) {
 }
 }  // namespace
 
-template <bool SAMPLE>
+// MARGIN (Dot / Euclid): the kernel ranks by the LOWER-BOUND score fma(-g_q, margin_row, score) -- see FusedBf16Params.
+// One more packed FMA per two elements of the epilogue and one more per-row constant staged per tile; the stage loop is
+// untouched.  Cosine runs the MARGIN = false instance (its row error is bounded relative to the row's own norm).
+template <bool SAMPLE, bool MARGIN>
 __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
     // three DISTINCT LDS objects, each access names its image at compile time (see kernels_fused_dma3.hip)
     __shared__ __attribute__((aligned(16))) char sImg0[STAGE_BYTES];
@@ -58,6 +61,8 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
     __shared__ __attribute__((aligned(16))) float sAlpha[2 * TR];
     __shared__ __attribute__((aligned(16))) float sBeta[2 * TR];
     __shared__ __attribute__((aligned(16))) uint32_t sMaskW[2 * TR];
+    __shared__ __attribute__((aligned(16))) float sMarg[MARGIN ? 2 * TR : 4];   // per-row error margin of a tile (same double buffering)
+    __shared__ float sG[MARGIN ? TQ : 1];                                        // g_q of the 256 queries (read in the epilogue only)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -210,8 +215,15 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
             VDB_DMA4(p.rowmask + (row >> 5), sMaskW + par * TR + cr);
         } else {
             VDB_DMA4(p.beta + row, sBeta + par * TR + cr);
+            if (MARGIN) VDB_DMA4(p.margin + row, sMarg + par * TR + cr);
         }
     };
+    if (MARGIN) {
+        // g_q lives in LDS, not in two more registers per lane held across the stage loop (the kernel sits at the 256-VGPR
+        // limit); the load is consumed here so that no ordinary load is pending inside the loop, and the prologue's barrier
+        // publishes the array
+        if (tid < TQ) { float g = p.qg[tid]; asm volatile("" : "+v"(g)); sG[tid] = g; }
+    }
 
     f32x16 acc[MT][QT];
 #pragma unroll
@@ -358,6 +370,9 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
             float best_a = __uint_as_float(0x7f800000u), best_b = best_a;   // sample mode: running group minima
             const float* al = sAlpha + par * TR + wr * 128 + 4 * h;
             const float* be = sBeta + par * TR + wr * 128 + 4 * h;
+            const float* mg = sMarg + (MARGIN ? par * TR + wr * 128 + 4 * h : 0);
+            f32x2 ng_a = {0.f, 0.f}, ng_b = {0.f, 0.f};
+            if (MARGIN) { const float ga = -sG[q_a], gb = -sG[q_b]; ng_a = f32x2{ga, ga}; ng_b = f32x2{gb, gb}; }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const uint32_t vbits = (uint32_t)(val[i >> 1] >> (32 * (i & 1) + 4 * h));
@@ -371,8 +386,14 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
                     const f32x2 al01 = {a4.x, a4.y}, al23 = {a4.z, a4.w}, be01 = {b4.x, b4.y}, be23 = {b4.z, b4.w};
                     const f32x2 pa01 = {acc[i][0][4 * j + 0], acc[i][0][4 * j + 1]}, pa23 = {acc[i][0][4 * j + 2], acc[i][0][4 * j + 3]};
                     const f32x2 pb01 = {acc[i][1][4 * j + 0], acc[i][1][4 * j + 1]}, pb23 = {acc[i][1][4 * j + 2], acc[i][1][4 * j + 3]};
-                    const f32x2 ra01 = __builtin_elementwise_fma(pa01, al01, be01), ra23 = __builtin_elementwise_fma(pa23, al23, be23);
-                    const f32x2 rb01 = __builtin_elementwise_fma(pb01, al01, be01), rb23 = __builtin_elementwise_fma(pb23, al23, be23);
+                    f32x2 ra01 = __builtin_elementwise_fma(pa01, al01, be01), ra23 = __builtin_elementwise_fma(pa23, al23, be23);
+                    f32x2 rb01 = __builtin_elementwise_fma(pb01, al01, be01), rb23 = __builtin_elementwise_fma(pb23, al23, be23);
+                    if (MARGIN) {
+                        const float4 m4 = *reinterpret_cast<const float4*>(mg + i * 32 + 8 * j);
+                        const f32x2 m01 = {m4.x, m4.y}, m23 = {m4.z, m4.w};
+                        ra01 = __builtin_elementwise_fma(ng_a, m01, ra01); ra23 = __builtin_elementwise_fma(ng_a, m23, ra23);
+                        rb01 = __builtin_elementwise_fma(ng_b, m01, rb01); rb23 = __builtin_elementwise_fma(ng_b, m23, rb23);
+                    }
                     const float sa0 = ra01.x, sa1 = ra01.y, sa2 = ra23.x, sa3 = ra23.y;
                     const float sb0 = rb01.x, sb1 = rb01.y, sb2 = rb23.x, sb3 = rb23.y;
                     const uint32_t rt0 = rowb + 8 * j;                  // tile-row of element 0
@@ -463,7 +484,8 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
 }
 
 void launch_fused_bf16p(const FusedBf16Params& p, hipStream_t s) {
-    hipLaunchKernelGGL(fused_bf16p_kernel<false>, dim3(p.n_wg), dim3(NT), 0, s, p);
+    if (p.margin) hipLaunchKernelGGL((fused_bf16p_kernel<false, true>), dim3(p.n_wg), dim3(NT), 0, s, p);
+    else hipLaunchKernelGGL((fused_bf16p_kernel<false, false>), dim3(p.n_wg), dim3(NT), 0, s, p);
 }
 
 }  // namespace vdb

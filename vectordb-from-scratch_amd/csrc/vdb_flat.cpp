@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -137,18 +138,20 @@ struct vdb_flat_index {
 
     // device store
     float* d_rows = nullptr; float* d_nd = nullptr; float* d_alpha = nullptr; float* d_beta = nullptr;
+    float* d_margin = nullptr;            // [cap] per-row error margin of the screening tier's lower-bound scores (Dot / Euclid; null under Cosine)
     uint64_t* d_row_ids = nullptr; uint32_t* d_live = nullptr; uint32_t* d_scalars = nullptr;  // [0]=nd2max bits [1]=zero count [2],[3]=max bf16 rounding error of a row (abs^2, rel^2)
     uint32_t cap_rows = 0;
     bool zero_valid = false; uint32_t zero_live = 0;
     DevBuf<uint32_t> d_idrank, d_rank2row; bool rank_valid = false;
 
     // search workspace
-    DevBuf<float> w_qp, w_qnorm, w_thr, w_qin, w_outd, w_qerr;
+    DevBuf<float> w_qp, w_qnorm, w_thr, w_qin, w_outd, w_qerr, w_qg, w_dbg;
+    uint32_t dbg_nq = 0; bool dbg_lb = false;             // vdb_flat_debug_screen_scores left this many prepared queries in the workspace
     DevBuf<uint64_t> w_dense, w_samp, w_pool, w_cand, w_exact, w_exsel, w_mask_ids, w_outi;
     DevBuf<uint32_t> w_cnt, w_rowmask, w_flags, w_outc, w_subcnt, w_depth;
     DevBuf<uint16_t> w_qb;                                  // bf16 copy of the padded queries (screening tier)
     // compact block of the queries the screening tier could not certify (re-run by the f32 tier)
-    DevBuf<float> w2_qp, w2_qnorm, w2_thr, w2_outd, w2_qerr;
+    DevBuf<float> w2_qp, w2_qnorm, w2_thr, w2_outd, w2_qerr, w2_qg;
     DevBuf<uint64_t> w2_outi, w2_cand;
     DevBuf<uint16_t> w2_qb;
     DevBuf<uint32_t> w2_outc, w2_flags, w2_qidx;
@@ -192,7 +195,7 @@ int grow(Index* ix, uint32_t need_rows) {
     if (need_rows <= ix->cap_rows) return VDB_OK;
     uint32_t cap = std::max<uint32_t>({need_rows, ix->cap_rows * 2u, 1024u});
     cap = round_up(cap, 256);
-    float *rows = nullptr, *nd = nullptr, *al = nullptr, *be = nullptr;
+    float *rows = nullptr, *nd = nullptr, *al = nullptr, *be = nullptr, *mg = nullptr;
     uint64_t* ids = nullptr;
     uint32_t* lv = nullptr;
     size_t row_bytes = (size_t)ix->ld * sizeof(float);
@@ -200,6 +203,7 @@ int grow(Index* ix, uint32_t need_rows) {
     HIP_TRY(hipMalloc((void**)&nd, (size_t)cap * 4));
     HIP_TRY(hipMalloc((void**)&al, (size_t)cap * 4));
     HIP_TRY(hipMalloc((void**)&be, (size_t)cap * 4));
+    if (ix->metric != vdb::COSINE) HIP_TRY(hipMalloc((void**)&mg, (size_t)cap * 4));
     HIP_TRY(hipMalloc((void**)&ids, (size_t)cap * 8));
     HIP_TRY(hipMalloc((void**)&lv, (size_t)cap / 8));
     hipStream_t s = ix->stream;
@@ -209,8 +213,10 @@ int grow(Index* ix, uint32_t need_rows) {
         HIP_TRY(hipMemcpyAsync(nd, ix->d_nd, (size_t)old * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(al, ix->d_alpha, (size_t)old * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(be, ix->d_beta, (size_t)old * 4, hipMemcpyDeviceToDevice, s));
+        if (mg) HIP_TRY(hipMemcpyAsync(mg, ix->d_margin, (size_t)old * 4, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(ids, ix->d_row_ids, (size_t)old * 8, hipMemcpyDeviceToDevice, s));
     }
+    if (mg) HIP_TRY(hipMemsetAsync(mg + old, 0, (size_t)(cap - old) * 4, s));   // rows past the last one are staged by the kernels (ragged tile)
     // zero the rest of the row block: the [dim, ld) padding columns must read as 0
     HIP_TRY(hipMemsetAsync((char*)rows + (size_t)old * row_bytes, 0, (size_t)(cap - old) * row_bytes, s));
     HIP_TRY(hipMemsetAsync(lv, 0, (size_t)cap / 8, s));
@@ -218,7 +224,9 @@ int grow(Index* ix, uint32_t need_rows) {
     if (ix->d_rows) {
         (void)hipFree(ix->d_rows); (void)hipFree(ix->d_nd); (void)hipFree(ix->d_alpha);
         (void)hipFree(ix->d_beta); (void)hipFree(ix->d_row_ids); (void)hipFree(ix->d_live);
+        if (ix->d_margin) (void)hipFree(ix->d_margin);
     }
+    ix->d_margin = mg;
     ix->d_rows = rows; ix->d_nd = nd; ix->d_alpha = al; ix->d_beta = be; ix->d_row_ids = ids; ix->d_live = lv;
     ix->cap_rows = cap;
     ix->live_dirty = true;
@@ -229,7 +237,9 @@ void free_store(Index* ix) {
     if (ix->d_rows) {
         (void)hipFree(ix->d_rows); (void)hipFree(ix->d_nd); (void)hipFree(ix->d_alpha);
         (void)hipFree(ix->d_beta); (void)hipFree(ix->d_row_ids); (void)hipFree(ix->d_live);
+        if (ix->d_margin) (void)hipFree(ix->d_margin);
     }
+    ix->d_margin = nullptr;
     ix->d_rows = ix->d_nd = ix->d_alpha = ix->d_beta = nullptr;
     ix->d_row_ids = nullptr; ix->d_live = nullptr;
     ix->cap_rows = 0;
@@ -241,7 +251,7 @@ void reset_rows(Index* ix) {
     ix->n_live = 0; ix->n_uploaded = 0; ix->dim = 0; ix->ld = 0; ix->ids_monotone = true;
     ix->zero_valid = false; ix->rank_valid = false; ix->live_dirty = false;
     free_store(ix);
-    if (ix->d_scalars) (void)hipMemsetAsync(ix->d_scalars, 0, 16, ix->stream);
+    if (ix->d_scalars) (void)hipMemsetAsync(ix->d_scalars, 0, 32, ix->stream);
 }
 
 void kill_row(Index* ix, uint32_t row) {
@@ -320,6 +330,51 @@ int add_one(Index* ix, uint64_t id, const float* v, size_t dim) {
     return VDB_OK;
 }
 
+// Certification coefficient (DESIGN.md "certified top-k"): worst-case rounding bound of the
+// MFMA fma chain plus the oracle's sequential fold, K = padded row length.  VDB_EPS_SCALE
+// scales it (diagnostics only).
+float eps_coef(const Index* ix) {
+    const double u = 5.9604644775390625e-08;   // 2^-24
+    double K = (double)ix->ld;
+    double c;
+    if (ix->metric == vdb::EUCLID) c = (K + 4.0) * u;
+    else if (ix->metric == vdb::COSINE) c = (2.0 * K + 16.0) * u;
+    else c = (2.0 * K + 2.0) * u;
+    c *= 1.1;
+    c *= ix->kn.eps_scale;                 // 1.0 outside the diagnostics build
+    return (float)c;
+}
+
+// f32 accumulation inside the bf16 MFMAs (products of two bf16 are exact in f32): at most K 2^-22 |q||d|, 5 % margin.
+// The operand-rounding part of the screening tier's error bound is evaluated per query in rerank_kernel from the
+// known |q - bf16(q)| and the per-index maxima of |d - bf16(d)| (row_stats_kernel).
+float c_acc_bf16(const Index* ix) {
+    double c = (double)ix->ld * 2.384185791015625e-07 * 1.05;
+    c *= ix->kn.eps_scale;                 // 1.0 outside the diagnostics build
+    return (float)c;
+}
+
+// The LOCAL form of the screening tier's certificate (Dot / Euclid).  For a row d and a query q the ranking score differs
+// from what the oracle's exact distance implies by at most
+//     Dot:     1.01 (|e_q||d| + 1.004 |q||e_d|) + (c_acc + eps) |q||d|
+//     Euclid:  2 x that with eps doubled, + eps |d|^2 (folded into the row's beta), + eps (|q|^2 + e_k^2) (query only, cert_test)
+// with e_q = q - bf16(q), e_d = d - bf16(d).  Everything row-dependent is of the form |q| A_d + |e_q| B_d;
+// with kappa = B_d / A_d of a typical row (relative bf16 rounding error 1e-3) it is bounded by g_q * M_d,
+//     g_q = |q| + kappa |e_q|   (query_prep),      M_d = max(A_d, B_d / kappa)   (row_stats: ONE more constant per row),
+// and the kernels rank by the lower-bound score  score - g_q M_d.  Any kappa > 0 is valid; this one makes the bound tight.
+struct MarginPlan { float m_e = 0, m_n = 0, m_b = 0, kappa = 0, beta_shrink = 0; };
+MarginPlan margin_plan(const Index* ix) {
+    MarginPlan mp;
+    if (ix->metric == vdb::COSINE) return mp;
+    const double eps = (double)eps_coef(ix), cacc = (double)c_acc_bf16(ix);
+    const double two = ix->metric == vdb::EUCLID ? 2.0 : 1.0;
+    const double Ae = two * 1.01 * 1.004, An = two * (cacc + eps), Bn = two * 1.01;
+    const double kappa = Bn / (Ae * 1.0e-3 + An);
+    mp.m_e = (float)Ae; mp.m_n = (float)(An * 1.000001); mp.m_b = (float)(Bn / kappa * 1.000001); mp.kappa = (float)(kappa * 1.000001);
+    mp.beta_shrink = ix->metric == vdb::EUCLID ? (float)eps : 0.0f;
+    return mp;
+}
+
 int flush(Index* ix) {
     hipStream_t s = ix->stream;
     uint32_t n = ix->n_rows();
@@ -331,8 +386,9 @@ int flush(Index* ix) {
                                (size_t)cnt * ix->ld * sizeof(float), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(ix->d_row_ids + first, ix->row_ids.data() + first, (size_t)cnt * 8,
                                hipMemcpyHostToDevice, s));
+        const MarginPlan mp = margin_plan(ix);
         vdb::RowStatsParams rp{ix->d_rows, ix->ld, ix->dim, first, n, ix->metric, ix->d_nd, ix->d_alpha,
-                               ix->d_beta, ix->d_scalars};
+                               ix->d_beta, ix->d_scalars, ix->d_margin, mp.m_e, mp.m_n, mp.m_b, mp.beta_shrink};
         vdb::launch_row_stats(rp, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(s));   // pending is host memory about to be released
@@ -379,30 +435,6 @@ int ensure_ranks(Index* ix) {
     HIP_TRY(hipStreamSynchronize(ix->stream));
     ix->rank_valid = true;
     return VDB_OK;
-}
-
-// Certification coefficient (DESIGN.md "certified top-k"): worst-case rounding bound of the
-// MFMA fma chain plus the oracle's sequential fold, K = padded row length.  VDB_EPS_SCALE
-// scales it (diagnostics only).
-float eps_coef(const Index* ix) {
-    const double u = 5.9604644775390625e-08;   // 2^-24
-    double K = (double)ix->ld;
-    double c;
-    if (ix->metric == vdb::EUCLID) c = (K + 4.0) * u;
-    else if (ix->metric == vdb::COSINE) c = (2.0 * K + 16.0) * u;
-    else c = (2.0 * K + 2.0) * u;
-    c *= 1.1;
-    c *= ix->kn.eps_scale;                 // 1.0 outside the diagnostics build
-    return (float)c;
-}
-
-// f32 accumulation inside the bf16 MFMAs (products of two bf16 are exact in f32): at most K 2^-22 |q||d|, 5 % margin.
-// The operand-rounding part of the screening tier's error bound is evaluated per query in rerank_kernel from the
-// known |q - bf16(q)| and the per-index maxima of |d - bf16(d)| (row_stats_kernel).
-float c_acc_bf16(const Index* ix) {
-    double c = (double)ix->ld * 2.384185791015625e-07 * 1.05;
-    c *= ix->kn.eps_scale;                 // 1.0 outside the diagnostics build
-    return (float)c;
 }
 
 // bf16 screening tier: the select delivers up to 256 candidates per query, sorted by score, and the re-rank goes
@@ -608,6 +640,7 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         vdb::FusedBf16Params fp{};
         fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w_qb.p + (size_t)q0 * ld;
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
+        fp.margin = ix->d_margin; fp.qg = ix->d_margin ? ix->w_qg.p + q0 : nullptr;
         fp.thr = ix->w_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
         fp.ablate = ix->kn.bf16_ablate;
         fp.n_sample = S; fp.sample_shift = pl.shift;
@@ -617,6 +650,7 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         vdb::SelectParams sp{};
         sp.keys = ix->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = KT;
         sp.out_stride = KT; sp.out_keys = ix->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->w_thr.p + q0; sp.ovf = nullptr;
+        if (ix->d_margin) { sp.shift_g = ix->w_qg.p + q0; sp.shift_m_bits = ix->d_scalars + 4; }   // plain-score sample -> lower-bound units
         vdb::launch_select(sp, nb, s);
 
         if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
@@ -649,7 +683,7 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         rp.out_ids = d_out_ids + (size_t)q0 * k; rp.out_dists = d_out_dists + (size_t)q0 * k;
         rp.out_counts = d_out_counts + q0; rp.out_stride = (uint32_t)k; rp.cert = d_cert + q0; rp.status = d_status;
         rp.thr = ix->w_thr.p + q0;
-        rp.qerr = ix->w_qerr.p + q0; rp.c_acc = c_acc_bf16(ix);
+        rp.qerr = ix->w_qerr.p + q0; rp.c_acc = c_acc_bf16(ix); rp.lb_scores = ix->d_margin ? 1u : 0u;
         rp.kp_first = round_up((uint32_t)k + 38u, 16u); rp.kp_step = 32;
         rp.thr_next = d_thr_next ? d_thr_next + q0 : nullptr;
         // diagnostics build: the first re-rank round overridden, the depth each query ended at printed
@@ -694,6 +728,7 @@ int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo
     if ((rc = ix->w2_qnorm.ensure(nfp))) return rc;
     if ((rc = ix->w2_thr.ensure(nfp))) return rc;
     if ((rc = ix->w2_qerr.ensure(nfp))) return rc;
+    if ((rc = ix->w2_qg.ensure(nfp))) return rc;
     if ((rc = ix->w2_qb.ensure((size_t)nfp * ld))) return rc;
     if ((rc = ix->w2_outi.ensure((size_t)nf * k))) return rc;
     if ((rc = ix->w2_outd.ensure((size_t)nf * k))) return rc;
@@ -709,7 +744,7 @@ int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo
     vdb::launch_gather_queries(ix->w_qp.p, ix->w_qnorm.p, ld, ix->w2_qidx.p, nf, nfp, ix->w2_qp.p, ix->w2_qnorm.p, ix->w2_thr.p, s);
     // bf16 image, |q - bf16(q)| and zeroed flags of the compact block (the rows are already padded: dim = ld)
     vdb::QueryPrepParams qp{ix->w2_qp.p, ld, nf, ix->w2_qp.p, ld, nfp, ix->w2_qnorm.p, ix->w2_thr.p, vdb::EUCLID, d_status,
-                            ix->w2_qb.p, ix->w2_qerr.p, d_cert2, d_ovf2};
+                            ix->w2_qb.p, ix->w2_qerr.p, ix->d_margin ? ix->w2_qg.p : nullptr, margin_plan(ix).kappa, d_cert2, d_ovf2};
     vdb::launch_query_prep(qp, s);
     HIP_TRY(hipMemcpyAsync(ix->w2_thr.p, cuts.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));   // padding queries keep -inf
     uint32_t* d_cand_cnt = ix->w_cnt.p + 2 * SUPER;
@@ -718,6 +753,7 @@ int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo
         vdb::FusedBf16Params fp{};
         fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w2_qb.p + (size_t)q0 * ld;
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
+        fp.margin = ix->d_margin; fp.qg = ix->d_margin ? ix->w2_qg.p + q0 : nullptr;
         fp.thr = ix->w2_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
 #ifdef VDB_DIAG
         if (!ix->kn.fused_pipe) vdb::launch_fused_bf16(fp, s);
@@ -845,10 +881,12 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
         if (ix->screen && plan_bf16(ix, n, k).kp) {
             if ((rc = ix->w_qb.ensure((size_t)bp_all * ld))) return rc;
             if ((rc = ix->w_qerr.ensure(bp_all))) return rc;
+            if ((rc = ix->w_qg.ensure(bp_all))) return rc;
             qb = ix->w_qb.p;
         }
         vdb::QueryPrepParams qp{d_q, (uint32_t)dim, nq32, ix->w_qp.p, ld, bp_all, ix->w_qnorm.p, ix->w_thr.p, ix->metric, d_status, qb,
-                                ix->w_qerr.p, flags_by_prep ? d_cert : nullptr, flags_by_prep ? d_ovf : nullptr};
+                                ix->w_qerr.p, (qb && ix->d_margin) ? ix->w_qg.p : nullptr, margin_plan(ix).kappa,
+                                flags_by_prep ? d_cert : nullptr, flags_by_prep ? d_ovf : nullptr};
         vdb::launch_query_prep(qp, s);
     }
 
@@ -1115,7 +1153,7 @@ int vdb_flat_create(int metric, int device, vdb_flat_index** out) {
         delete ix;
         return fail(VDB_ERR_DEVICE, "hipStreamCreate failed");
     }
-    if (hipMalloc((void**)&ix->d_scalars, 16) != hipSuccess || hipMemset(ix->d_scalars, 0, 16) != hipSuccess) {
+    if (hipMalloc((void**)&ix->d_scalars, 32) != hipSuccess || hipMemset(ix->d_scalars, 0, 32) != hipSuccess) {
         (void)hipStreamDestroy(ix->stream);
         delete ix;
         return fail(VDB_ERR_DEVICE, "hipMalloc failed");
@@ -1135,7 +1173,7 @@ void vdb_flat_destroy(vdb_flat_index* ix) {
     ix->w_dense.release(); ix->w_samp.release(); ix->w_pool.release(); ix->w_cand.release(); ix->w_exact.release();
     ix->w_exsel.release(); ix->w_mask_ids.release(); ix->w_outi.release();
     ix->w_qb.release(); ix->w_qerr.release(); ix->w2_qp.release(); ix->w2_qnorm.release(); ix->w2_thr.release(); ix->w2_outd.release();
-    ix->w2_qerr.release(); ix->w2_cand.release(); ix->w2_qb.release();
+    ix->w2_qerr.release(); ix->w2_cand.release(); ix->w2_qb.release(); ix->w_qg.release(); ix->w2_qg.release(); ix->w_dbg.release();
     ix->w2_outi.release(); ix->w2_outc.release(); ix->w2_flags.release(); ix->w2_qidx.release();
     ix->w_cnt.release(); ix->w_subcnt.release(); ix->w_rowmask.release(); ix->w_flags.release(); ix->w_outc.release(); ix->w_depth.release();
     if (ix->h_flags) (void)hipHostFree(ix->h_flags);
@@ -1217,8 +1255,9 @@ int vdb_flat_add_bulk_device(vdb_flat_index* ix, const uint64_t* ids, uint64_t f
     }
     ix->n_live += (uint32_t)n;
     HIP_TRY(hipMemcpyAsync(ix->d_row_ids + first, ix->row_ids.data() + first, n * 8, hipMemcpyHostToDevice, s));
+    const MarginPlan mp = margin_plan(ix);
     vdb::RowStatsParams rp{ix->d_rows, ix->ld, ix->dim, first, first + (uint32_t)n, ix->metric, ix->d_nd,
-                           ix->d_alpha, ix->d_beta, ix->d_scalars};
+                           ix->d_alpha, ix->d_beta, ix->d_scalars, ix->d_margin, mp.m_e, mp.m_n, mp.m_b, mp.beta_shrink};
     vdb::launch_row_stats(rp, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -1482,7 +1521,7 @@ int vdb_flat_distances_batch(vdb_flat_index* ix, const float* queries, size_t nq
     HIP_TRY(hipMemcpyAsync(ix->w_rowmask.p, prow.data(), total * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ix->w_rowmask.p + total, pq.data(), total * 4, hipMemcpyHostToDevice, s));
     vdb::QueryPrepParams qp{ix->w_qin.p, (uint32_t)dim, nq32, ix->w_qp.p, ld, bp, ix->w_qnorm.p, ix->w_thr.p, vdb::EUCLID,
-                            ix->w_flags.p, nullptr, nullptr, nullptr, nullptr};   // metric EUCLID here: zero norms are judged per PAIR below
+                            ix->w_flags.p, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr};   // metric EUCLID here: zero norms are judged per PAIR below
     vdb::launch_query_prep(qp, s);
     vdb::PairDistParams pp{ix->d_rows, ld, (uint32_t)dim, ix->w_qp.p, ix->w_qnorm.p, ix->d_nd, ix->w_rowmask.p + total,
                            ix->w_rowmask.p, (uint32_t)total, ix->metric, ix->w_outd.p, ix->w_flags.p};
@@ -1535,6 +1574,125 @@ int vdb_flat_last_stats_ex(const vdb_flat_index* ix, uint64_t* out, size_t n) {
     if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     for (size_t i = 0; i < n; ++i) out[i] = i < 16 ? ix->stats[i] : 0;
     return VDB_OK;
+}
+
+// ------------------------------------------------------------------ certificate diagnostics (include/vdb_flat.h)
+int vdb_flat_debug_screen_scores(vdb_flat_index* ix, const float* queries, size_t nq, size_t dim, int raw, float* out_scores,
+                                 float* out_qinfo, double* out_consts) {
+    if (!ix || !queries || !out_scores || !nq) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    if (nq > SUPER) return fail(VDB_ERR_INVALID_ARGUMENT, "at most %u queries per call", SUPER);
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc;
+    if ((rc = set_device(ix))) return rc;
+    if ((rc = flush(ix))) return rc;
+    const uint32_t n = ix->n_uploaded, ld = ix->ld;
+    if (!n) return fail(VDB_ERR_INVALID_ARGUMENT, "empty index");
+    if (ix->dim != dim) return fail_dim(dim, ix->dim);
+    if (!ix->misfits.empty()) return fail(VDB_ERR_INVALID_ARGUMENT, "rows of another dimension are stored");
+    hipStream_t s = ix->stream;
+    const uint32_t tile = vdb::fused_bf16_tile_rows();
+    const uint32_t nblk = (n + tile - 1) / tile;
+    const uint32_t n_wg = std::min<uint32_t>((uint32_t)ix->n_cu, nblk);
+    const uint32_t n_sub = vdb::fused_bf16_subpools_per_query(n_wg);
+    const uint32_t capl = 64u * ((nblk + n_wg - 1) / n_wg);            // every row of a workgroup's range fits its sub-pools
+    const size_t pool_keys = (size_t)SUPER * n_sub * capl;
+    if (pool_keys * 8 > ((size_t)6 << 30)) return fail(VDB_ERR_INVALID_ARGUMENT, "index too large for the score dump");
+    if ((rc = ix->w_qin.ensure(nq * dim))) return rc;
+    if ((rc = ix->w_qp.ensure((size_t)SUPER * ld))) return rc;
+    if ((rc = ix->w_qnorm.ensure(SUPER))) return rc;
+    if ((rc = ix->w_thr.ensure(SUPER))) return rc;
+    if ((rc = ix->w_qb.ensure((size_t)SUPER * ld))) return rc;
+    if ((rc = ix->w_qerr.ensure(SUPER))) return rc;
+    if ((rc = ix->w_qg.ensure(SUPER))) return rc;
+    if ((rc = ix->w_flags.ensure(4 + 3 * (size_t)SUPER))) return rc;
+    if ((rc = ix->w_pool.ensure(pool_keys))) return rc;
+    if ((rc = ix->w_subcnt.ensure((size_t)SUPER * n_sub))) return rc;
+    if ((rc = ix->w_dbg.ensure(nq * (size_t)n))) return rc;
+    ix->status_dirty = true;
+    HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, 16, s));
+    HIP_TRY(hipMemcpyAsync(ix->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    const bool lb = ix->d_margin && !raw;
+    vdb::QueryPrepParams qp{ix->w_qin.p, (uint32_t)dim, (uint32_t)nq, ix->w_qp.p, ld, SUPER, ix->w_qnorm.p, ix->w_thr.p, vdb::EUCLID,
+                            ix->w_flags.p, ix->w_qb.p, ix->w_qerr.p, ix->d_margin ? ix->w_qg.p : nullptr, margin_plan(ix).kappa,
+                            nullptr, nullptr};
+    vdb::launch_query_prep(qp, s);
+    std::vector<float> thr(nq, std::numeric_limits<float>::infinity());            // everything passes; padding queries keep -inf
+    HIP_TRY(hipMemcpyAsync(ix->w_thr.p, thr.data(), nq * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(ix->w_dbg.p, 0xff, nq * (size_t)n * 4, s));            // NaN pattern = no key for this (query, row)
+    vdb::FusedBf16Params fp{};
+    fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w_qb.p; fp.alpha = ix->d_alpha; fp.beta = ix->d_beta;
+    fp.margin = lb ? ix->d_margin : nullptr; fp.qg = lb ? ix->w_qg.p : nullptr;
+    fp.rowmask = ix->d_live; fp.thr = ix->w_thr.p; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
+    vdb::launch_fused_bf16p(fp, s);                                              // the PRODUCTION filter pass
+    vdb::launch_pool_to_dense(ix->w_pool.p, ix->w_subcnt.p, n_sub, capl, (uint32_t)nq, n, ix->w_dbg.p, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_scores, ix->w_dbg.p, nq * (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    std::vector<float> qn(nq), qe(nq), qg(nq, 0.0f);
+    uint32_t sc[8] = {0};
+    HIP_TRY(hipMemcpyAsync(qn.data(), ix->w_qnorm.p, nq * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(qe.data(), ix->w_qerr.p, nq * 4, hipMemcpyDeviceToHost, s));
+    if (ix->d_margin) HIP_TRY(hipMemcpyAsync(qg.data(), ix->w_qg.p, nq * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(sc, ix->d_scalars, 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (out_qinfo)
+        for (size_t q = 0; q < nq; ++q) { out_qinfo[4 * q] = qn[q]; out_qinfo[4 * q + 1] = qe[q]; out_qinfo[4 * q + 2] = qg[q]; out_qinfo[4 * q + 3] = 0.0f; }
+    if (out_consts) {
+        auto f = [](uint32_t b) { float v; memcpy(&v, &b, 4); return (double)v; };
+        const MarginPlan mp = margin_plan(ix);
+        out_consts[0] = eps_coef(ix); out_consts[1] = c_acc_bf16(ix); out_consts[2] = mp.kappa;
+        out_consts[3] = std::sqrt(f(sc[0])); out_consts[4] = std::sqrt(f(sc[2])); out_consts[5] = std::sqrt(f(sc[3]));   // max |d|, max |e_d|, max |e_d|/|d|
+        out_consts[6] = lb ? 1.0 : 0.0; out_consts[7] = (double)ld;
+    }
+    ix->dbg_nq = (uint32_t)nq; ix->dbg_lb = lb;
+    return VDB_OK;
+}
+
+size_t vdb_flat_debug_rows(const vdb_flat_index* ix) { return ix ? ix->row_ids.size() : 0; }
+
+int vdb_flat_debug_row_info(vdb_flat_index* ix, float* out, size_t n_rows) {
+    if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc;
+    if ((rc = set_device(ix))) return rc;
+    if ((rc = flush(ix))) return rc;
+    const size_t n = std::min<size_t>(n_rows, ix->n_uploaded);
+    std::vector<float> a(n), b(n), c(n), d(n, 0.0f);
+    if (n) {
+        HIP_TRY(hipMemcpy(a.data(), ix->d_nd, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(b.data(), ix->d_alpha, n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(c.data(), ix->d_beta, n * 4, hipMemcpyDeviceToHost));
+        if (ix->d_margin) HIP_TRY(hipMemcpy(d.data(), ix->d_margin, n * 4, hipMemcpyDeviceToHost));
+    }
+    for (size_t i = 0; i < n; ++i) { out[4 * i] = a[i]; out[4 * i + 1] = b[i]; out[4 * i + 2] = c[i]; out[4 * i + 3] = d[i]; }
+    return VDB_OK;
+}
+
+int vdb_flat_debug_cert_probe(vdb_flat_index* ix, const uint32_t* qi, const float* T, const float* ek, size_t n, uint32_t* out) {
+    if (!ix || !qi || !T || !ek || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    int rc;
+    if ((rc = set_device(ix))) return rc;
+    if (!ix->dbg_nq) return fail(VDB_ERR_INVALID_ARGUMENT, "call vdb_flat_debug_screen_scores first");
+    if (n == 0) return VDB_OK;
+    if (n > 0x7fffffffull) return fail(VDB_ERR_INVALID_ARGUMENT, "too many probes");
+    for (size_t i = 0; i < n; ++i)
+        if (qi[i] >= ix->dbg_nq) return fail(VDB_ERR_INVALID_ARGUMENT, "query index %u out of range", qi[i]);
+    hipStream_t s = ix->stream;
+    DevBuf<uint32_t> d_qi, d_out; DevBuf<float> d_T, d_ek;
+    auto done = [&](int r) { d_qi.release(); d_out.release(); d_T.release(); d_ek.release(); return r; };
+    if ((rc = d_qi.ensure(n)) || (rc = d_out.ensure(n)) || (rc = d_T.ensure(n)) || (rc = d_ek.ensure(n))) return done(rc);
+    if (hipMemcpyAsync(d_qi.p, qi, n * 4, hipMemcpyHostToDevice, s) != hipSuccess || hipMemcpyAsync(d_T.p, T, n * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_ek.p, ek, n * 4, hipMemcpyHostToDevice, s) != hipSuccess)
+        return done(fail(VDB_ERR_DEVICE, "copy failed"));
+    // the same parameter block the screening tier's re-rank gets (pass_bf16)
+    vdb::RerankParams rp{};
+    rp.metric = ix->metric; rp.eps_coef = eps_coef(ix); rp.nd2max_bits = ix->d_scalars; rp.qnorm = ix->w_qnorm.p; rp.ld = ix->ld;
+    rp.qerr = ix->w_qerr.p; rp.c_acc = c_acc_bf16(ix); rp.lb_scores = ix->dbg_lb ? 1u : 0u;
+    vdb::launch_cert_probe(rp, d_qi.p, d_T.p, d_ek.p, (uint32_t)n, d_out.p, s);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d_out.p, n * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return done(fail(VDB_ERR_DEVICE, "cert probe failed"));
+    return done(VDB_OK);
 }
 
 int vdb_flat_set_tiers(vdb_flat_index* ix, unsigned flags) {
@@ -1593,7 +1751,7 @@ int pairs_begin(vdb_flat_index* ix, const float* queries, size_t nq, size_t dim)
     if ((rc = ix->w_flags.ensure(4))) return rc;
     HIP_TRY(hipMemcpyAsync(ix->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
     vdb::QueryPrepParams qp{ix->w_qin.p, (uint32_t)dim, (uint32_t)nq, ix->w_qp.p, ld, bp, ix->w_qnorm.p, ix->w_thr.p, vdb::EUCLID,
-                            ix->w_flags.p, nullptr, nullptr, nullptr, nullptr};   // metric EUCLID: zero norms are judged per pair
+                            ix->w_flags.p, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr};   // metric EUCLID: zero norms are judged per pair
     vdb::launch_query_prep(qp, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));

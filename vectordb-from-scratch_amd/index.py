@@ -276,6 +276,43 @@ class GpuFlatIndex(Index):
         if rc:
             _raise(rc)
 
+    # ---- certificate diagnostics (include/vdb_flat.h "Diagnostics of the screening tier's CERTIFICATE")
+    def debug_screen_scores(self, queries, raw=False):
+        """(scores [nq, rows] f32, qinfo [nq, 4], consts dict) from the production filter kernel with open thresholds."""
+        qs = np.ascontiguousarray(queries, dtype=np.float32)
+        nq, dim = qs.shape
+        n = int(self._L.vdb_flat_debug_rows(self._h))
+        scores = np.empty((nq, n), dtype=np.float32)
+        qinfo = np.zeros((nq, 4), dtype=np.float32)
+        consts = np.zeros(8, dtype=np.float64)
+        rc = self._L.vdb_flat_debug_screen_scores(self._h, _fp(qs), nq, dim, int(bool(raw)), _fp(scores), _fp(qinfo),
+                                                  consts.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        if rc:
+            _raise(rc)
+        keys = ["eps_coef", "c_acc", "kappa", "nd_max", "ed_max", "rho_max", "lower_bound_scores", "ld"]
+        return scores, qinfo, dict(zip(keys, consts.tolist()))
+
+    def debug_row_info(self):
+        """[rows, 4] f32: exact-order norm, alpha, beta, margin."""
+        n = int(self._L.vdb_flat_debug_rows(self._h))
+        out = np.zeros((n, 4), dtype=np.float32)
+        rc = self._L.vdb_flat_debug_row_info(self._h, _fp(out), n)
+        if rc:
+            _raise(rc)
+        return out
+
+    def debug_cert_probe(self, qi, T, ek):
+        """The production certification test for (prepared query qi[i], score bound T[i], k-th exact distance ek[i])."""
+        qi = np.ascontiguousarray(qi, dtype=np.uint32)
+        T = np.ascontiguousarray(T, dtype=np.float32)
+        ek = np.ascontiguousarray(ek, dtype=np.float32)
+        out = np.zeros(qi.size, dtype=np.uint32)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        rc = self._L.vdb_flat_debug_cert_probe(self._h, qi.ctypes.data_as(u32p), _fp(T), _fp(ek), qi.size, out.ctypes.data_as(u32p))
+        if rc:
+            _raise(rc)
+        return out
+
     def set_profile(self, on=True):
         rc = self._L.vdb_flat_set_profile(self._h, int(bool(on)))
         if rc:
