@@ -307,6 +307,49 @@ def test_mmap_vector_file_bulk_load(vdb, tmp_path):
     assert ix2.len() == 0
 
 
+def test_vector_file_header_that_overflows_the_size_check(vdb, tmp_path):
+    """`8 + count*dim*4` wraps a size_t for a crafted header (dim = count = 2^31 -> product 2^64 = 0), the
+    truncation check passed on an 8-byte file and the loader read far past the mapping.  Also dim > 16384 is refused."""
+    for dim, count in ((2 ** 31, 2 ** 31), (2 ** 30, 2 ** 32 - 1), (16385, 1), (4096, 2 ** 32 - 1)):
+        path = tmp_path / f"bad_{dim}_{count}.bin"
+        with open(path, "wb") as f:
+            f.write(np.array([dim, count], dtype="<u4").tobytes())
+            f.write(b"\0" * 64)
+        ix = vdb.GpuFlatIndex(vdb.DistanceMetric.Euclidean)
+        with pytest.raises(vdb.VectorDbError):
+            ix.load_vector_file(str(path))
+        assert ix.len() == 0
+
+
+def test_duplicate_ids_inside_one_device_batch_are_last_wins(vdb):
+    """vdb_flat_add_bulk_device kept BOTH rows of an id that occurs twice in one batch (len over-counted, the id
+    returned twice).  HashMap::insert is last-wins (flat_index.rs:38-41), like the host path."""
+    import torch
+    rng = np.random.default_rng(5)
+    n, d = 3000, 24
+    rows = rng.random((n, d), dtype=np.float32)
+    ids = np.arange(n, dtype=np.uint64)
+    ids[100] = 7          # id 7 twice: rows 7 and 100 -> row 100 wins
+    ids[2000] = 7         # ... and a third time: row 2000 wins
+    ids[2999] = 1500      # id 1500: row 2999 wins
+    t = torch.from_numpy(rows).cuda()
+    ix = vdb.GpuFlatIndex(vdb.DistanceMetric.Euclidean, keep_host_copy=False)
+    ix.add_bulk_device(t.data_ptr(), n, d, ids=ids)
+    assert ix.len() == n - 3
+    live = np.ones(n, dtype=np.uint8)
+    live[[7, 100, 1500]] = 0
+    q = np.concatenate([rows[[7, 100, 2000, 1500, 2999]], rng.random((3, d), dtype=np.float32)])
+    check_against_oracle(vdb, 0, rows, q, 10, ids=ids, ix=ix, live=live)
+    assert np.array_equal(ix.get_vector(7).data, rows[2000]) and np.array_equal(ix.get_vector(1500).data, rows[2999])
+    ix.remove(7)
+    assert ix.len() == n - 4 and ix.get_vector(7) is None
+    # a second batch that overwrites ids of the first one AND repeats an id inside itself
+    rows2 = rng.random((4, d), dtype=np.float32)
+    t2 = torch.from_numpy(rows2).cuda()
+    ix.add_bulk_device(t2.data_ptr(), 4, d, ids=np.array([5, 9, 5, 10**9], dtype=np.uint64))
+    assert ix.len() == n - 4 - 2 + 3 and np.array_equal(ix.get_vector(5).data, rows2[2])
+
+
 def test_concurrent_searches_from_several_threads(vdb):
     """search may be called concurrently on one handle (the server holds RwLock::read() around it,
     src/server/routes.rs:244,:342); ctypes releases the GIL, the library serialises device submission."""

@@ -34,6 +34,11 @@ constexpr int B_BYTES = TQ * B_ROWB;             // 16 KB
 constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 48 KB
 constexpr int MT = 4, QT = 2;                    // MFMA tiles per wave: 4 x 32 rows, 2 x 32 queries
 
+#ifdef VDB_DIAG
+constexpr bool kDiag = true;                     // ablate bits 32 / 64 below exist in the diagnostics build only
+#else
+constexpr bool kDiag = false;
+#endif
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
@@ -428,12 +433,17 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
             const uint32_t e_ = (uint32_t)__builtin_ctz(hm_);                                          \
             hm_ &= hm_ - 1u;                                                                           \
             const float sc_ = e_ == 0 ? (S0) : e_ == 1 ? (S1) : e_ == 2 ? (S2) : (S3);                 \
-            if (PCNT < p.capl) POOL[PCNT] = make_raw_key(sc_, tr0 + rt0 + e_);                         \
+            if (!(kDiag && (p.ablate & 32u)) && PCNT < p.capl) POOL[PCNT] = make_raw_key(sc_, tr0 + rt0 + e_); /* diag 32: count only */ \
             ++PCNT;                                                                                    \
         }                                                                                              \
     }
+                        if (kDiag && (p.ablate & 64u)) {            // diag 64: the branch is taken, the append is not executed
+                            if (__builtin_expect(ma != 0ull, 0)) { asm volatile("s_nop 1" ::: "memory"); ++pcnt_a; }
+                            if (__builtin_expect(mb != 0ull, 0)) { asm volatile("s_nop 1" ::: "memory"); ++pcnt_b; }
+                        } else {
                         if (__builtin_expect(ma != 0ull, 0)) VDB_APPEND(sa0, sa1, sa2, sa3, thr_a, pool_a, pcnt_a)
                         if (__builtin_expect(mb != 0ull, 0)) VDB_APPEND(sb0, sb1, sb2, sb3, thr_b, pool_b, pcnt_b)
+                        }
 #undef VDB_APPEND
                     }
                 }

@@ -55,6 +55,17 @@ int fail_dim(size_t expected, size_t actual) {
     return fail(VDB_ERR_DIMENSION_MISMATCH, "Dimension mismatch: expected %zu, got %zu", expected, actual);
 }
 
+int vdb_guard_fail(const char* what) { return fail(VDB_ERR_DEVICE, "internal error: %s", what); }
+
+// No C++ exception may cross the C ABI (ctypes, a Rust FFI caller: undefined behaviour or abort).  Every extern "C" entry
+// point that can allocate runs its body through this.
+template <class F> int guarded(F&& body) noexcept {
+    try { return body(); }
+    catch (const std::bad_alloc&) { return vdb_guard_fail("out of host memory"); }
+    catch (const std::exception& e) { return vdb_guard_fail(e.what()); }
+    catch (...) { return vdb_guard_fail("unknown C++ exception"); }
+}
+
 #define HIP_TRY(expr)                                                                           \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
@@ -1120,6 +1131,7 @@ void vdb_last_error(char* buf, size_t cap, size_t* expected, size_t* actual) {
 }
 
 int vdb_flat_create(int metric, int device, vdb_flat_index** out) {
+    return guarded([&]() -> int {
     if (!out) return fail(VDB_ERR_INVALID_ARGUMENT, "out is null");
     *out = nullptr;
     if (metric < 0 || metric > 2) return fail(VDB_ERR_INVALID_ARGUMENT, "unknown metric %d", metric);
@@ -1160,6 +1172,7 @@ int vdb_flat_create(int metric, int device, vdb_flat_index** out) {
     }
     *out = ix;
     return VDB_OK;
+    });
 }
 
 void vdb_flat_destroy(vdb_flat_index* ix) {
@@ -1186,15 +1199,18 @@ void vdb_flat_destroy(vdb_flat_index* ix) {
 }
 
 int vdb_flat_add(vdb_flat_index* ix, uint64_t id, const float* v, size_t dim) {
+    return guarded([&]() -> int {
     if (!ix || (!v && dim)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
     return add_one(ix, id, v, dim);
+    });
 }
 
 int vdb_flat_add_bulk(vdb_flat_index* ix, const uint64_t* ids, uint64_t first_id, const float* rows, size_t n,
                       size_t dim) {
+    return guarded([&]() -> int {
     if (!ix || (!rows && n && dim)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
     int rc = set_device(ix);
@@ -1210,10 +1226,12 @@ int vdb_flat_add_bulk(vdb_flat_index* ix, const uint64_t* ids, uint64_t first_id
         }
     }
     return VDB_OK;
+    });
 }
 
 int vdb_flat_add_bulk_device(vdb_flat_index* ix, const uint64_t* ids, uint64_t first_id, const float* d_rows,
                              size_t n, size_t dim) {
+    return guarded([&]() -> int {
     if (!ix || (!d_rows && n)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return VDB_OK;
     if (dim == 0) return fail(VDB_ERR_INVALID_ARGUMENT, "dim must be > 0");
@@ -1251,9 +1269,12 @@ int vdb_flat_add_bulk_device(vdb_flat_index* ix, const uint64_t* ids, uint64_t f
         ix->row_ids.push_back(id);
         if ((row >> 5) >= ix->live.size()) ix->live.push_back(0u);
         ix->live[row >> 5] |= 1u << (row & 31);
-        ix->id2row[id] = row;
+        ++ix->n_live;
+        // the same id twice in ONE batch: HashMap::insert is last-wins (flat_index.rs:38-41) -- the earlier row of this
+        // call dies (ids stored before the call were removed above)
+        auto ins = ix->id2row.emplace(id, row);
+        if (!ins.second) { kill_row(ix, ins.first->second); ins.first->second = row; }
     }
-    ix->n_live += (uint32_t)n;
     HIP_TRY(hipMemcpyAsync(ix->d_row_ids + first, ix->row_ids.data() + first, n * 8, hipMemcpyHostToDevice, s));
     const MarginPlan mp = margin_plan(ix);
     vdb::RowStatsParams rp{ix->d_rows, ix->ld, ix->dim, first, first + (uint32_t)n, ix->metric, ix->d_nd,
@@ -1266,9 +1287,11 @@ int vdb_flat_add_bulk_device(vdb_flat_index* ix, const uint64_t* ids, uint64_t f
     ix->zero_valid = false;
     ix->rank_valid = false;
     return VDB_OK;
+    });
 }
 
 int vdb_flat_load_vector_file(vdb_flat_index* ix, const char* path, uint64_t first_id, size_t* out_count) {
+    return guarded([&]() -> int {
     if (!ix || !path) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     if (out_count) *out_count = 0;
     int fd = open(path, O_RDONLY);
@@ -1286,7 +1309,9 @@ int vdb_flat_load_vector_file(vdb_flat_index* ix, const char* path, uint64_t fir
     const size_t dim = le32(0), count = le32(4);                                      // mmap.rs:161-172
     int rc = VDB_OK;
     if (dim == 0 && count) rc = fail(VDB_ERR_INVALID_ARGUMENT, "vector file with dimension 0");
-    else if ((size_t)st.st_size < 8 + count * dim * 4) rc = fail(VDB_ERR_INVALID_ARGUMENT, "vector file truncated: %zu rows of %zu floats need %zu bytes", count, dim, 8 + count * dim * 4);
+    else if (dim > 16384) rc = fail(VDB_ERR_INVALID_ARGUMENT, "vector file dimension %zu exceeds the supported 16384", dim);
+    // (count * dim * 4 can wrap a size_t -- both come from the file -- so the check divides instead)
+    else if (dim && count > ((size_t)st.st_size - 8) / 4 / dim) rc = fail(VDB_ERR_INVALID_ARGUMENT, "vector file truncated: %zu rows of %zu floats do not fit %zu bytes", count, dim, (size_t)st.st_size);
     else if (count) {
         // the body starts at byte 8, so rows are 4-byte aligned; x86 is little-endian like the file
         rc = vdb_flat_add_bulk(ix, nullptr, first_id, (const float*)(b + 8), count, dim);
@@ -1295,17 +1320,21 @@ int vdb_flat_load_vector_file(vdb_flat_index* ix, const char* path, uint64_t fir
     munmap(map, (size_t)st.st_size);
     if (rc == VDB_OK && out_count) *out_count = count;
     return rc;
+    });
 }
 
 int vdb_flat_remove(vdb_flat_index* ix, uint64_t id) {
+    return guarded([&]() -> int {
     if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
     std::lock_guard<std::mutex> g(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
     return remove_id(ix, id);
+    });
 }
 
 int vdb_flat_get_vector(vdb_flat_index* ix, uint64_t id, float* out, size_t cap, size_t* dim) {
+    return guarded([&]() -> int {
     if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
     std::lock_guard<std::mutex> g(ix->mu);
     int rc = set_device(ix);
@@ -1328,6 +1357,7 @@ int vdb_flat_get_vector(vdb_flat_index* ix, uint64_t id, float* out, size_t cap,
         HIP_TRY(hipMemcpy(out, ix->d_rows + (size_t)row * ix->ld, ncopy * sizeof(float), hipMemcpyDeviceToHost));
     }
     return VDB_OK;
+    });
 }
 
 size_t vdb_flat_len(const vdb_flat_index* ix) { return ix ? ix->n_live + ix->misfits.size() : 0; }
@@ -1335,6 +1365,7 @@ int vdb_flat_metric(const vdb_flat_index* ix) { return ix ? ix->metric : -1; }
 size_t vdb_flat_dim(const vdb_flat_index* ix) { return ix ? ix->dim : 0; }
 
 int vdb_flat_reserve(vdb_flat_index* ix, size_t rows, size_t dim) {
+    return guarded([&]() -> int {
     if (!ix || !dim) return fail(VDB_ERR_INVALID_ARGUMENT, "bad argument");
     std::lock_guard<std::mutex> g(ix->mu);
     int rc = set_device(ix);
@@ -1348,9 +1379,11 @@ int vdb_flat_reserve(vdb_flat_index* ix, size_t rows, size_t dim) {
     if (rows > 0xfffffff0ull) return fail(VDB_ERR_INVALID_ARGUMENT, "more than 2^32 rows per index");
     if ((rc = flush(ix))) return rc;
     return grow(ix, (uint32_t)rows);
+    });
 }
 
 int vdb_flat_flush(vdb_flat_index* ix) {
+    return guarded([&]() -> int {
     if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
     std::lock_guard<std::mutex> g(ix->mu);
     int rc = set_device(ix);
@@ -1358,26 +1391,31 @@ int vdb_flat_flush(vdb_flat_index* ix) {
     if ((rc = flush(ix))) return rc;
     if (ix->metric == vdb::COSINE && ix->n_uploaded) return ensure_zero_count(ix);
     return VDB_OK;
+    });
 }
 
 int vdb_flat_search_batch_device(vdb_flat_index* ix, const float* d_queries, size_t nq, size_t dim, size_t k,
                                  const uint64_t* d_id_mask, size_t mask_bits, uint64_t* d_out_ids,
                                  float* d_out_dists, uint32_t* d_out_counts, void* stream) {
+    return guarded([&]() -> int {
     if (!ix || (nq && (!d_queries || !d_out_counts || (k && (!d_out_ids || !d_out_dists)))))
         return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
     return search_device(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts,
                          (hipStream_t)stream);
+    });
 }
 
 int vdb_flat_search_batch_device_begin(vdb_flat_index* ix, const float* d_queries, size_t nq, size_t dim, size_t k,
                                        const uint64_t* d_id_mask, size_t mask_bits, uint64_t* d_out_ids,
                                        float* d_out_dists, uint32_t* d_out_counts, int32_t* d_code, void* stream) {
+    return guarded([&]() -> int {
     if (!ix || (nq && (!d_queries || !d_out_counts || (k && (!d_out_ids || !d_out_dists)))))
         return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     ix->mu.lock();
     if (ix->begin_locked) { ix->mu.unlock(); return fail(VDB_ERR_INVALID_ARGUMENT, "a search is already pending on this handle"); }
-    int rc = search_part1(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts, (hipStream_t)stream);
+    // (the handle is locked by hand here: an exception must not skip the unlock below)
+    int rc = guarded([&]() -> int { return search_part1(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts, (hipStream_t)stream); });
     if (rc == VDB_OK && d_code) {
         hipStream_t s = stream ? (hipStream_t)stream : ix->stream;
         if (ix->ctx.pending) vdb::launch_write_code(ix->w_flags.p, d_code, s);
@@ -1396,21 +1434,25 @@ int vdb_flat_search_batch_device_begin(vdb_flat_index* ix, const float* d_querie
     }
     ix->begin_locked = true;                                   // released by vdb_flat_search_batch_device_finish (same thread)
     return VDB_OK;
+    });
 }
 
 int vdb_flat_search_batch_device_finish(vdb_flat_index* ix, int* changed) {
+    return guarded([&]() -> int {
     if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
     if (!ix->begin_locked) return fail(VDB_ERR_INVALID_ARGUMENT, "no search pending on this handle");
-    int rc = search_part2(ix, changed);
+    int rc = guarded([&]() -> int { return search_part2(ix, changed); });
     ix->ctx.pending = false;
     ix->begin_locked = false;
     ix->mu.unlock();
     return rc;
+    });
 }
 
 int vdb_flat_search_batch(vdb_flat_index* ix, const float* queries, size_t nq, size_t dim, const size_t* ks,
                           size_t k, const uint64_t* id_mask, size_t mask_bits, size_t kstride, uint64_t* out_ids,
                           float* out_dists, size_t* out_counts) {
+    return guarded([&]() -> int {
     if (!ix || (nq && (!queries || !out_counts))) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     size_t kmax = k;
     if (ks) {
@@ -1461,17 +1503,21 @@ int vdb_flat_search_batch(vdb_flat_index* ix, const float* queries, size_t nq, s
         }
     }
     return VDB_OK;
+    });
 }
 
 int vdb_flat_search(vdb_flat_index* ix, const float* query, size_t dim, size_t k, uint64_t* out_ids,
                     float* out_dists, size_t* out_count) {
+    return guarded([&]() -> int {
     if (!out_count) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     return vdb_flat_search_batch(ix, query, 1, dim, nullptr, k, nullptr, 0, k, out_ids, out_dists, out_count);
+    });
 }
 
 int vdb_merge_topk_device(int device, const uint64_t* d_part_ids, const float* d_part_dists,
                           const uint32_t* d_part_counts, size_t nparts, size_t nq, size_t k, uint64_t* d_out_ids,
                           float* d_out_dists, uint32_t* d_out_counts, void* stream) {
+    return guarded([&]() -> int {
     if (!d_part_ids || !d_part_dists || !d_part_counts || !d_out_ids || !d_out_dists || !d_out_counts)
         return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     if (nparts * k > 2048) return fail(VDB_ERR_INVALID_ARGUMENT, "nparts*k = %zu exceeds 2048", nparts * k);
@@ -1480,10 +1526,12 @@ int vdb_merge_topk_device(int device, const uint64_t* d_part_ids, const float* d
                             d_out_ids, d_out_dists, d_out_counts, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return VDB_OK;
+    });
 }
 
 int vdb_flat_distances_batch(vdb_flat_index* ix, const float* queries, size_t nq, size_t dim, const size_t* offsets,
                              const uint64_t* ids, float* out_dists) {
+    return guarded([&]() -> int {
     if (!ix || !offsets || (nq && !queries)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     const size_t total = offsets[nq];
     if (total && (!ids || !out_dists)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
@@ -1534,11 +1582,13 @@ int vdb_flat_distances_batch(vdb_flat_index* ix, const float* queries, size_t nq
     if (st & vdb::ST_ZERO_QUERY)
         return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
     return VDB_OK;   // a NaN distance is returned as NaN (only the sort in FlatIndex::search panics on it)
+    });
 }
 
 int vdb_merge_topk_packed_device(int device, const int32_t* d_packed, size_t nparts, size_t words_per_part, size_t nq,
                                  size_t k, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
                                  uint32_t* d_out_status, void* stream) {
+    return guarded([&]() -> int {
     if (!d_packed || !d_out_ids || !d_out_dists || !d_out_counts)
         return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     if (nparts * k > 2048) return fail(VDB_ERR_INVALID_ARGUMENT, "nparts*k = %zu exceeds 2048", nparts * k);
@@ -1549,9 +1599,11 @@ int vdb_merge_topk_packed_device(int device, const int32_t* d_packed, size_t npa
                              d_out_dists, d_out_counts, d_out_status, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return VDB_OK;
+    });
 }
 
 int vdb_flat_set_profile(vdb_flat_index* ix, int on) {
+    return guarded([&]() -> int {
     if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
     std::lock_guard<std::mutex> g(ix->mu);
     int rc = set_device(ix);
@@ -1562,23 +1614,29 @@ int vdb_flat_set_profile(vdb_flat_index* ix, int on) {
     }
     ix->profile = on != 0;
     return VDB_OK;
+    });
 }
 
 int vdb_flat_last_stats(const vdb_flat_index* ix, uint64_t out[8]) {
+    return guarded([&]() -> int {
     if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     memcpy(out, ix->stats, 8 * sizeof(uint64_t));
     return VDB_OK;
+    });
 }
 
 int vdb_flat_last_stats_ex(const vdb_flat_index* ix, uint64_t* out, size_t n) {
+    return guarded([&]() -> int {
     if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     for (size_t i = 0; i < n; ++i) out[i] = i < 16 ? ix->stats[i] : 0;
     return VDB_OK;
+    });
 }
 
 // ------------------------------------------------------------------ certificate diagnostics (include/vdb_flat.h)
 int vdb_flat_debug_screen_scores(vdb_flat_index* ix, const float* queries, size_t nq, size_t dim, int raw, float* out_scores,
                                  float* out_qinfo, double* out_consts) {
+    return guarded([&]() -> int {
     if (!ix || !queries || !out_scores || !nq) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     if (nq > SUPER) return fail(VDB_ERR_INVALID_ARGUMENT, "at most %u queries per call", SUPER);
     std::lock_guard<std::mutex> g(ix->mu);
@@ -1645,11 +1703,13 @@ int vdb_flat_debug_screen_scores(vdb_flat_index* ix, const float* queries, size_
     }
     ix->dbg_nq = (uint32_t)nq; ix->dbg_lb = lb;
     return VDB_OK;
+    });
 }
 
 size_t vdb_flat_debug_rows(const vdb_flat_index* ix) { return ix ? ix->row_ids.size() : 0; }
 
 int vdb_flat_debug_row_info(vdb_flat_index* ix, float* out, size_t n_rows) {
+    return guarded([&]() -> int {
     if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
     int rc;
@@ -1665,9 +1725,11 @@ int vdb_flat_debug_row_info(vdb_flat_index* ix, float* out, size_t n_rows) {
     }
     for (size_t i = 0; i < n; ++i) { out[4 * i] = a[i]; out[4 * i + 1] = b[i]; out[4 * i + 2] = c[i]; out[4 * i + 3] = d[i]; }
     return VDB_OK;
+    });
 }
 
 int vdb_flat_debug_cert_probe(vdb_flat_index* ix, const uint32_t* qi, const float* T, const float* ek, size_t n, uint32_t* out) {
+    return guarded([&]() -> int {
     if (!ix || !qi || !T || !ek || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
     int rc;
@@ -1693,20 +1755,25 @@ int vdb_flat_debug_cert_probe(vdb_flat_index* ix, const uint32_t* qi, const floa
         hipStreamSynchronize(s) != hipSuccess)
         return done(fail(VDB_ERR_DEVICE, "cert probe failed"));
     return done(VDB_OK);
+    });
 }
 
 int vdb_flat_set_tiers(vdb_flat_index* ix, unsigned flags) {
+    return guarded([&]() -> int {
     if (!ix || (flags & ~7u)) return fail(VDB_ERR_INVALID_ARGUMENT, "flags must be a combination of VDB_TIERS_*");
     std::lock_guard<std::mutex> g(ix->mu);
     ix->tiers = flags;
     return VDB_OK;
+    });
 }
 
 int vdb_flat_set_screen(vdb_flat_index* ix, int mode) {
+    return guarded([&]() -> int {
     if (!ix || mode < 0 || mode > 1) return fail(VDB_ERR_INVALID_ARGUMENT, "mode must be 0 (f32 MFMA tier only) or 1 (bf16 screening tier first)");
     std::lock_guard<std::mutex> g(ix->mu);
     ix->screen = mode;
     return VDB_OK;
+    });
 }
 
 }  // extern "C"

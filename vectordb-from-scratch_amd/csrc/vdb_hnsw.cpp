@@ -201,6 +201,14 @@ struct LayerSearch {
     }
 };
 
+// No C++ exception may cross the C ABI (std::bad_alloc from nodes.resize(id + 1) on a sparse id, vector growth in a search).
+template <class F> int guarded(F&& body) noexcept {
+    try { return body(); }
+    catch (const std::bad_alloc&) { return vdb_internal::set_error(VDB_ERR_DEVICE, "internal error: out of host memory"); }
+    catch (const std::exception& e) { return vdb_internal::set_error(VDB_ERR_DEVICE, e.what()); }
+    catch (...) { return vdb_internal::set_error(VDB_ERR_DEVICE, "internal error: unknown C++ exception"); }
+}
+
 int zero_norm_error() {
     return vdb_internal::set_error(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
 }
@@ -304,8 +312,19 @@ int add_rows(Graph* g, const uint64_t* ids, uint64_t first_id, const float* rows
     if (dim == 0) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "zero-dimensional vectors are not indexable");
     if (g->count == 0 && !g->has_ep) g->dim = dim;
     if (dim != g->dim) return vdb_internal::set_dim_error(g->dim, dim);
+    // The graph is a Vec indexed by id in the reference too (graph.rs:78, :249-251 resize_with(id + 1)), so a huge sparse id
+    // costs id + 1 slots there as here; the device mirror addresses nodes with 32 bits, so larger ids are refused up front
+    // (and an allocation failure of the resize is caught at the boundary instead of unwinding through it).
+    for (size_t i = 0; i < n; ++i)
+        if ((ids ? ids[i] : first_id + i) >= 0xfffffff0ull)
+            return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "HNSW node ids must be below 2^32 - 16");
     int rc;
     if ((rc = vdb_flat_add_bulk(g->flat, ids, first_id, rows, n, dim))) return rc;
+    // When insert number i fails (zero-norm Cosine pair), the reference has stored node i without links and has not seen
+    // the vectors after it (mod.rs:37-42 returns at the first error): the rows after i leave the row store again.
+    auto rollback_after = [&](size_t i_fail) {
+        for (size_t t = i_fail + 1; t < n; ++t) (void)vdb_flat_remove(g->flat, ids ? ids[t] : first_id + t);
+    };
     std::vector<float> scan;
     constexpr size_t CHUNK = 256;
     for (size_t c0 = 0; c0 < n; c0 += CHUNK) {
@@ -318,10 +337,10 @@ int add_rows(Graph* g, const uint64_t* ids, uint64_t first_id, const float* rows
             // every distance this insert can ask for: the new vector against the rows stored before it
             scan.resize(std::max<size_t>(row, 1));
             if (row) {
-                if ((rc = vdb_internal::query_vs_rows(g->flat, (uint32_t)i, row, scan.data()))) return rc;
+                if ((rc = vdb_internal::query_vs_rows(g->flat, (uint32_t)i, row, scan.data()))) { rollback_after(c0 + i - 1); return rc; }
                 g->stats[1]++;
             }
-            if ((rc = insert_node(g, id, row, levels ? levels[c0 + i] : level1, scan.data()))) return rc;
+            if ((rc = insert_node(g, id, row, levels ? levels[c0 + i] : level1, scan.data()))) { rollback_after(c0 + i); return rc; }
         }
     }
     return VDB_OK;
@@ -335,6 +354,7 @@ extern "C" {
 
 int vdb_hnsw_create(int metric, size_t m, size_t ef_construction, size_t ef_search, uint64_t seed, int device,
                     vdb_hnsw_index** out) {
+    return guarded([&]() -> int {
     if (!out) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "out is null");
     *out = nullptr;
     if (m < 2) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "m must be >= 2");
@@ -346,6 +366,7 @@ int vdb_hnsw_create(int metric, size_t m, size_t ef_construction, size_t ef_sear
     g->ef_search = ef_search; g->ml = 1.0 / std::log((double)m); g->rng = seed;              // graph.rs:49-59
     *out = g;
     return VDB_OK;
+    });
 }
 
 void vdb_hnsw_destroy(vdb_hnsw_index* g) {
@@ -356,18 +377,23 @@ void vdb_hnsw_destroy(vdb_hnsw_index* g) {
 }
 
 int vdb_hnsw_add(vdb_hnsw_index* g, uint64_t id, const float* v, size_t dim, long level) {
+    return guarded([&]() -> int {
     if (!g || !v) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> lk(g->mu);
     return add_rows(g, &id, 0, v, 1, dim, nullptr, level);
+    });
 }
 
 int vdb_hnsw_add_bulk(vdb_hnsw_index* g, const uint64_t* ids, uint64_t first_id, const float* rows, size_t n, size_t dim) {
+    return guarded([&]() -> int {
     if (!g || (!rows && n)) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> lk(g->mu);
     return add_rows(g, ids, first_id, rows, n, dim, nullptr, -1);
+    });
 }
 
 int vdb_hnsw_remove(vdb_hnsw_index* g, uint64_t id) {             // graph.rs:345-381
+    return guarded([&]() -> int {
     if (!g) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null handle");
     std::lock_guard<std::mutex> lk(g->mu);
     if (!g->node(id)) return VDB_OK;
@@ -390,6 +416,7 @@ int vdb_hnsw_remove(vdb_hnsw_index* g, uint64_t id) {             // graph.rs:34
         g->max_level = g->has_ep ? best : 0;
     }
     return rc;
+    });
 }
 
 }  // extern "C"
@@ -623,6 +650,7 @@ extern "C" {
 
 int vdb_hnsw_search_batch(vdb_hnsw_index* g, const float* queries, size_t nq, size_t dim, size_t k, size_t ef,
                           uint64_t* out_ids, float* out_dists, size_t* out_counts) {
+    return guarded([&]() -> int {
     if (!g || (nq && (!queries || !out_counts || (k && (!out_ids || !out_dists)))))
         return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> lk(g->mu);
@@ -653,24 +681,29 @@ int vdb_hnsw_search_batch(vdb_hnsw_index* g, const float* queries, size_t nq, si
         }
     }
     return VDB_OK;
+    });
 }
 
 int vdb_hnsw_set_traversal(vdb_hnsw_index* g, int host_only, size_t host_threads) {
+    return guarded([&]() -> int {
     if (!g) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null handle");
     std::lock_guard<std::mutex> lk(g->mu);
     g->host_only = host_only != 0;
     g->host_threads = std::min<size_t>(host_threads, 64);
     return VDB_OK;
+    });
 }
 
 size_t vdb_hnsw_len(const vdb_hnsw_index* g) { return g ? g->count : 0; }
 int vdb_hnsw_metric(const vdb_hnsw_index* g) { return g ? g->metric : -1; }
 
 int vdb_hnsw_get_vector(vdb_hnsw_index* g, uint64_t id, float* out, size_t cap, size_t* dim) {
+    return guarded([&]() -> int {
     if (!g) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null handle");
     std::lock_guard<std::mutex> lk(g->mu);
     if (!g->node(id)) return vdb_internal::set_error(VDB_ERR_NOT_FOUND, "Vector not found");
     return vdb_flat_get_vector(g->flat, id, out, cap, dim);
+    });
 }
 
 long vdb_hnsw_neighbors(const vdb_hnsw_index* g, uint64_t id, size_t layer, uint64_t* out, size_t cap) {
@@ -685,17 +718,21 @@ long vdb_hnsw_node_level(const vdb_hnsw_index* g, uint64_t id) {
     return n ? (long)n->level : -1;
 }
 int vdb_hnsw_entry_point(const vdb_hnsw_index* g, uint64_t* id, size_t* max_level) {
+    return guarded([&]() -> int {
     if (!g) return 0;
     if (id) *id = g->ep;
     if (max_level) *max_level = g->max_level;
     return g->has_ep ? 1 : 0;
+    });
 }
 int vdb_hnsw_stats(const vdb_hnsw_index* g, uint64_t out[6]) {
+    return guarded([&]() -> int {
     if (!g || !out) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null argument");
     memcpy(out, g->stats, sizeof(g->stats));
     out[4] = g->device_queries;
     out[5] = g->host_redone;
     return VDB_OK;
+    });
 }
 
 }  // extern "C"
