@@ -15,7 +15,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert os.path.exists(path)
     L = ctypes.CDLL(path)
     declared = set()
-    for h in ("vdb_flat.h", "vdb_hnsw.h"):
+    for h in ("vdb_flat.h", "vdb_hnsw.h", "vdb_shard.h"):
         header = open(os.path.join(ROOT, "include", h)).read()
         header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)            # declarations only, not the prose
         declared |= set(re.findall(r"\b(vdb_[a-z0-9_]+)\s*\(", header))

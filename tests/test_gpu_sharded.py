@@ -145,3 +145,66 @@ def test_two_half_search_for_the_single_sync_exchange():
     assert len(ix3.search(vdb.Vector(q[0]), 3)) == 3            # the handle is unlocked and usable again
     with pytest.raises(vdb.VectorDbError):
         ix3.search_batch_device_finish()                        # no search pending
+
+
+def test_c_abi_shard_group_single_rank_runs_the_full_rccl_exchange(vdb):
+    """include/vdb_shard.h on the one-GPU box: a single-rank RCCL communicator (unique id, ncclCommInitRank, ncclCommCount),
+    the local search in two halves writing into the packed buffer, ncclAllGather, the merge kernel, the status reduction.
+    Results must equal the plain search and the oracle; a clean batch costs ONE collective, a batch whose first tier
+    leaves queries for the host costs TWO; errors come back as the reference's error classes."""
+    import torch
+    from vectordb_from_scratch_amd.sharded import ShardGroup, group_search
+    rng = np.random.default_rng(31)
+    n, d, B, k = 90_000, 48, 33, 10
+    dev = torch.device("cuda", 0)
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    grp = ShardGroup(ShardGroup.unique_id(), 0, 1, device=0)
+    assert grp.world() == 1
+    for metric in (0, 1, 2):
+        ix = vdb.GpuFlatIndex(vdb.DistanceMetric(metric), keep_host_copy=False)
+        ix.add_bulk(rows, first_id=1000)                        # global ids of this "shard"
+        search = group_search(grp, ix)
+        gi, gd, gc = (t.cpu().numpy() for t in search(torch.from_numpy(q).to(dev), k))
+        st = grp.last_stats()
+        assert st["collectives"] == 1 and st["ranks"] == 1 and st["local_pending"] == 0, st
+        pi, pdist, pc = ix.search_batch_arrays(q, k)
+        assert np.array_equal(gi.astype(np.uint64), pi) and np.array_equal(gd.view(np.uint32), pdist.view(np.uint32)) and np.all(gc == k)
+        for b in (0, 17, B - 1):
+            oi, od = oracle.flat_search(metric, rows, q[b], k, ids=np.arange(1000, 1000 + n, dtype=np.uint64))
+            assert np.array_equal(gi[b].astype(np.uint64), oi) and np.array_equal(gd[b].view(np.uint32), od.view(np.uint32))
+    # the first tier cannot certify (every row 300 times): VDB_PENDING_HOST -> second exchange, results still the oracle's
+    base = rng.random((300, d), dtype=np.float32)
+    rows2 = np.concatenate([base] * 300, 0)
+    q2 = np.ascontiguousarray(np.tile(base[:3], (11, 1))[:B])
+    ix2 = vdb.GpuFlatIndex(vdb.DistanceMetric(0), keep_host_copy=False)
+    ix2.add_bulk(rows2)
+    gi, gd, gc = (t.cpu().numpy() for t in group_search(grp, ix2)(torch.from_numpy(q2).to(dev), k))
+    st = grp.last_stats()
+    assert st["collectives"] == 2 and st["local_pending"] == 1, st
+    for b in (0, 1, 20):
+        oi, od = oracle.flat_search(0, rows2, q2[b], k)
+        assert np.array_equal(gi[b].astype(np.uint64), oi) and np.array_equal(gd[b], od)
+    # errors: a zero-norm query under Cosine (found on the device, reported by finish) and a dimension mismatch (refused by begin)
+    ix3 = vdb.GpuFlatIndex(vdb.DistanceMetric(1), keep_host_copy=False)
+    ix3.add_bulk(rows)
+    qz = q.copy()
+    qz[5] = 0.0
+    with pytest.raises(vdb.InvalidVector):
+        group_search(grp, ix3)(torch.from_numpy(qz).to(dev), k)
+    with pytest.raises(vdb.DimensionMismatch):
+        group_search(grp, ix3)(torch.from_numpy(np.ascontiguousarray(q[:, :20])).to(dev), k)
+    gi, _, gc = group_search(grp, ix3)(torch.from_numpy(q).to(dev), k)      # group and handle stay usable
+    assert int(gc.min()) == k
+    # an empty shard contributes nothing; k = 0 and nq = 0 involve no collective
+    ix4 = vdb.GpuFlatIndex(vdb.DistanceMetric(0), keep_host_copy=False)
+    _, _, gc = group_search(grp, ix4)(torch.from_numpy(q).to(dev), k)
+    assert int(gc.max()) == 0
+    # world = 1 WITHOUT an id: no RCCL at all, the plain local search
+    g1 = ShardGroup(None, 0, 1, device=0)
+    ix = vdb.GpuFlatIndex(vdb.DistanceMetric(2), keep_host_copy=False)
+    ix.add_bulk(rows)
+    gi, gd, gc = (t.cpu().numpy() for t in group_search(g1, ix)(torch.from_numpy(q).to(dev), k))
+    assert g1.last_stats()["collectives"] == 0
+    pi, pdist, _ = ix.search_batch_arrays(q, k)
+    assert np.array_equal(gi.astype(np.uint64), pi) and np.array_equal(gd.view(np.uint32), pdist.view(np.uint32))

@@ -103,6 +103,100 @@ def test_world2_gloo_sharded_search(metric, poison):
     assert res == {0: "ok", 1: "ok"}
 
 
+class _TwoHalf:
+    """A two-half local search (begin / finish, like gpu_local_search over vdb_flat_search_batch_device_begin/_finish)
+    backed by the oracle, whose behaviour per rank is scripted: 'clean' | 'pending' | 'raise_at_begin' | 'raise_at_finish'."""
+
+    def __init__(self, base, mode):
+        self.base, self.mode, self._todo = base, mode, None
+
+    def __call__(self, queries, k, outs=None):
+        return self.base(queries, k, outs)
+
+    def begin(self, queries, k, outs, code_view):
+        from vectordb_from_scratch_amd.error import InvalidVector
+        if self.mode == "raise_at_begin":
+            raise InvalidVector("Cannot compute cosine distance with zero vector")
+        res = self.base(queries, k)
+        if self.mode == "clean":
+            for o, r in zip(outs, res):
+                o.copy_(r)
+            code_view[0] = 0
+        else:                                    # the first tier left queries for the host: partial results are NOT final
+            for o in outs:
+                o.zero_()
+            code_view[0] = 100
+            self._todo = (outs, res)
+
+    def finish(self):
+        from vectordb_from_scratch_amd.error import InvalidVector
+        if self.mode == "raise_at_finish":
+            raise InvalidVector("Cannot compute cosine distance with zero vector")
+        if self._todo is not None:
+            outs, res = self._todo
+            for o, r in zip(outs, res):
+                o.copy_(r)
+            self._todo = None
+            return True
+        return False
+
+
+def _worker_two_half(rank, world, port, modes, result_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_package
+    load_package()
+    import oracle
+    from vectordb_from_scratch_amd.error import InvalidVector
+    from vectordb_from_scratch_amd.sharded import ShardedSearcher, merge_topk_torch, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    try:
+        rng = np.random.default_rng(7)
+        n, d, B, k = 2000, 16, 6, 5
+        rows = rng.random((n, d), dtype=np.float32)
+        queries = rng.random((B, d), dtype=np.float32)
+        lo, hi = shard_range(n, rank, world)
+        local = _TwoHalf(_oracle_local_search(rows[lo:hi], np.arange(lo, hi, dtype=np.uint64), 0), modes[rank])
+        searcher = ShardedSearcher(local, rank=rank, world=world, merge=merge_topk_torch)
+        try:
+            ids, dists, counts = searcher.search_batch(torch.from_numpy(queries), k)
+            ok = True
+            for b in range(B):
+                oi, od = oracle.flat_search(0, rows, queries[b], k)
+                ok &= int(counts[b]) == len(oi) and np.array_equal(ids[b].numpy().astype(np.uint64), oi) and np.array_equal(dists[b].numpy(), od)
+            result_q.put((rank, "ok" if ok else "mismatch", searcher.collectives))
+        except InvalidVector:
+            result_q.put((rank, "InvalidVector", searcher.collectives))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("modes,expect,collectives", [
+    (("clean", "clean"), "ok", 1),
+    (("pending", "clean"), "ok", 2),                       # one rank rewrote its partial results: everybody exchanges twice
+    (("raise_at_begin", "pending"), "InvalidVector", 1),    # ADVICE r1: this pair used to deadlock (rank 1 waited in exchange 2)
+    (("pending", "raise_at_begin"), "InvalidVector", 1),
+    (("raise_at_finish", "clean"), "InvalidVector", 2),     # pending after the first tier, then the fallback fails: the error travels in exchange 2
+    (("raise_at_begin", "raise_at_begin"), "InvalidVector", 1),
+])
+def test_world2_two_half_search_keeps_the_ranks_in_step(modes, expect, collectives):
+    """Every rank performs the same number of collectives whatever happens locally, and every rank reports the failure."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_two_half, args=(r, 2, port, modes, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res = {r: (what, n) for r, what, n in got}
+    assert res == {0: (expect, collectives), 1: (expect, collectives)}, res
+
+
 def test_shard_range_covers_everything():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import load_package

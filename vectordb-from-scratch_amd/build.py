@@ -12,7 +12,7 @@ def _stale():
         return True
     t = os.path.getmtime(LIB)
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
-    srcs.append(os.path.join(HERE, "..", "include", "vdb_flat.h"))
+    srcs += [os.path.join(HERE, "..", "include", h) for h in ("vdb_flat.h", "vdb_hnsw.h", "vdb_shard.h")]
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
