@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the FlatIndex hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): FlatIndex 1M x 768 f32, cosine, batch = 256 queries, k = 10,
-synthetic uniform[0,1) data (the reference benches' distribution, benches/search_bench.rs:6-13),
-seeded.  One "step" = one batched search of the whole index with queries and outputs resident in
-HBM.  With --gpus N > 1 the SAME 1M-row index is sharded by row over N ranks (one process per
-GPU, RCCL): local search -> one all-gather of the partial top-k -> merge ("scaling": "strong").
-
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement), with
-"roofline" (the dominant kernel, HIP-event timed on its launch stream), "f32_mfma_tier" (the f32-input MFMA tier
-measured on the same index in the same run; results identical) and "cpu_baseline"
-(the CPU oracle = port of the reference algorithm, 1 core, bounded query sample).
+Workloads (BASELINE.json `configs`); synthetic uniform[0,1) data like the reference's benches
+(benches/search_bench.rs:6-13), seeded.  One "step" = one batched search with queries and outputs resident in HBM.
+
+  c2 (default, the configuration BASELINE.json's metric is quoted on)
+      FlatIndex 1M x 768 f32, cosine, batch = 256, k = 10.  --gpus N shards the SAME 1M rows ("scaling": "strong").
+  c3  FlatIndex 10M x 768 f32, dot, batch = 1024, k = 100, row-sharded over 8 GPUs: every rank builds ITS 1.25M-row shard
+      on the device (per-GPU work fixed, "scaling": "weak"; --gpus 8 is the 10M-row job of BASELINE configs[2]).
+  c4  FlatIndex 1M x 1536 f32, Euclidean, batch = 256, k = 10, metadata eq-filter (25 % of the rows) compiled by
+      VectorStore.compile_filter from string metadata into the device bitmask applied before top-k.
+
+With N > 1 the exchange (RCCL all-gather of the partial top-k + merge) runs behind the C ABI (include/vdb_shard.h);
+torch.distributed only launches the ranks, broadcasts the RCCL unique id and takes the MAX of the timings.
+
+Prints ONE JSON line on rank 0 (the driver contract) with
+  "roofline"        the dominant kernel, HIP-event timed on its launch stream, on BOTH axes of SURVEY 8(d) with the
+                    binding one named; "traffic" = PMC HBM bytes per launch of the profiled run the line cites;
+  "f32_exact_tier"  the same index and queries through the f32-input MFMA tier only (the contract's f32 axis), results
+                    compared bit for bit with the default path;
+  "gauss_dataset"   the same size on unit-normalised Gaussian rows (the harder distribution of SURVEY 8(d));
+  "cpu_baseline"    the CPU oracle = port of the reference algorithm, 1 core, bounded query sample.
 """
 import argparse
 import importlib.util
@@ -27,11 +37,21 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
-N_ROWS, DIM, BATCH, K = 1_000_000, 768, 256, 10
-METRIC = 1                      # cosine
+CONFIGS = {
+    "c2": dict(rows=1_000_000, dim=768, batch=256, k=10, metric=1, scaling="strong",
+               workload="FlatIndex 1M x 768 f32, cosine, batch=256 queries, k=10 (BASELINE configs[1])"),
+    "c3": dict(rows_per_rank=1_250_000, dim=768, batch=1024, k=100, metric=2, scaling="weak",
+               workload="FlatIndex 10M x 768 f32, dot product, batch=1024, k=100, row-sharded 1.25M rows per GPU (BASELINE configs[2]; "
+                        "the 10M-row job is --gpus 8)"),
+    "c4": dict(rows=1_000_000, dim=1536, batch=256, k=10, metric=0, scaling="strong",
+               workload="FlatIndex 1M x 1536 f32, Euclidean, batch=256, k=10, metadata eq filter as a device bitmask before top-k "
+                        "(BASELINE configs[3])"),
+}
 CHUNK = 125_000                 # generation granule: data is identical for every --gpus value
 PEAK_F32_MFMA_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input MFMA
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (not the 2:1-sparsity headline)
 PEAK_HBM_GBS = 8000.0
+PALETTE = ["red", "green", "blue", "amber"]
 
 
 def load_package():
@@ -50,25 +70,47 @@ def load_package():
 DATA = "uniform"                # "uniform": [0,1) like the reference's benches; "gauss": unit-normalised Gaussian rows
 
 
-def gen_chunk(c, n, dim, device):
+def gen_chunk(c, n, dim, device, data=None):
     g = torch.Generator(device=device)
     g.manual_seed(1000 + c)                      # db seed family (db seed 1, query seed 2)
-    if DATA == "gauss":
+    if (data or DATA) == "gauss":
         x = torch.randn((n, dim), generator=g, device=device, dtype=torch.float32)
         return x / x.norm(dim=1, keepdim=True)
     return torch.rand((n, dim), generator=g, device=device, dtype=torch.float32)
 
 
-def gen_queries(nq, dim, device):
+def gen_queries(nq, dim, device, data=None):
     g = torch.Generator(device=device)
     g.manual_seed(2)
-    if DATA == "gauss":
+    if (data or DATA) == "gauss":
         return torch.randn((nq, dim), generator=g, device=device, dtype=torch.float32)
     return torch.rand((nq, dim), generator=g, device=device, dtype=torch.float32)
 
 
-def index_ld(dim):
-    return (dim + 31) // 32 * 32                                # padded row stride of the device store
+def build_index(vdb, metric, lo, hi, n_rows, dim, device, local_rank, data=None):
+    """Rows lo..hi of the global, chunk-seeded matrix, generated on the device and handed over in HBM."""
+    index = vdb.GpuFlatIndex(vdb.DistanceMetric(metric), device=local_rank, keep_host_copy=False)
+    index.reserve(hi - lo, dim)
+    chunk = min(CHUNK, n_rows)
+    for c in range(lo // chunk, (hi + chunk - 1) // chunk):
+        c0, c1 = c * chunk, min((c + 1) * chunk, n_rows)
+        block = gen_chunk(c, c1 - c0, dim, device, data)
+        a, b = max(lo, c0), min(hi, c1)
+        part = block[a - c0:b - c0].contiguous()
+        torch.cuda.synchronize()
+        index.add_bulk_device(part.data_ptr(), b - a, dim, first_id=a)
+        del block, part
+    index.flush()
+    return index
+
+
+def host_rows(n_rows, dim, device, data=None):
+    chunk = min(CHUNK, n_rows)
+    out = np.empty((n_rows, dim), dtype=np.float32)
+    for c in range((n_rows + chunk - 1) // chunk):
+        c0, c1 = c * chunk, min((c + 1) * chunk, n_rows)
+        out[c0:c1] = gen_chunk(c, c1 - c0, dim, device, data).cpu().numpy()
+    return out
 
 
 def main():
@@ -76,22 +118,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--rows", type=int, default=N_ROWS, help="override the index size (parity/debug only)")
-    ap.add_argument("--dim", type=int, default=DIM)
-    ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--k", type=int, default=K)
-    ap.add_argument("--metric", type=int, default=METRIC)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE.json workload (default c2 = the configuration the metric is quoted on)")
+    ap.add_argument("--rows", type=int, default=0, help="override the index size (parity/debug only)")
+    ap.add_argument("--dim", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--k", type=int, default=0)
+    ap.add_argument("--metric", type=int, default=-1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-f32-tier", action="store_true", help="skip the side measurement of the f32 MFMA tier")
-    ap.add_argument("--data", default="uniform", choices=["uniform", "gauss"], help="uniform[0,1) (the reference benches' distribution) or unit-normalised Gaussian rows")
+    ap.add_argument("--no-gauss", action="store_true", help="skip the side measurement on unit-normalised Gaussian rows")
+    ap.add_argument("--data", default="uniform", choices=["uniform", "gauss"], help="distribution of the HEADLINE index")
     ap.add_argument("--screen", type=int, default=1, help="1: bf16 screening tier first (default); 0: f32 MFMA tier only")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
-    ap.add_argument("--filter-mod", type=int, default=0, help="config-4 style pre-filter: only ids with id %% m == 0 are eligible")
+    ap.add_argument("--backend", default="nccl", help="nccl = RCCL behind the C ABI (default); gloo: the torch.distributed mirror of the call pattern, to rehearse several ranks on one GPU")
     args = ap.parse_args()
 
     global DATA
     DATA = args.data
+    cfg = dict(CONFIGS[args.config])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -112,140 +156,186 @@ def main():
 
     vdb = load_package()
     vdb.build()
-    from vectordb_from_scratch_amd.sharded import ShardedSearcher, gpu_local_search, shard_range
+    from vectordb_from_scratch_amd.sharded import (ShardGroup, ShardedSearcher, gpu_local_search, group_search, shard_range)
 
-    n_rows, dim, B, k = args.rows, args.dim, args.batch, args.k
-    lo, hi = shard_range(n_rows, rank, world)
+    dim = args.dim or cfg["dim"]
+    B = args.batch or cfg["batch"]
+    k = args.k or cfg["k"]
+    metric = cfg["metric"] if args.metric < 0 else args.metric
+    if "rows_per_rank" in cfg:                                      # weak scaling: every rank owns a full-size shard
+        per = args.rows or cfg["rows_per_rank"]
+        n_rows, lo, hi = per * world, per * rank, per * (rank + 1)
+    else:
+        n_rows = args.rows or cfg["rows"]
+        lo, hi = shard_range(n_rows, rank, world)
 
-    # ---- build this rank's shard directly in HBM (rows lo..hi of the global, chunk-seeded matrix)
-    index = vdb.GpuFlatIndex(vdb.DistanceMetric(args.metric), device=local_rank, keep_host_copy=False)
-    index.reserve(hi - lo, dim)
-    chunk = min(CHUNK, n_rows)
-    for c in range(lo // chunk, (hi + chunk - 1) // chunk):
-        c0, c1 = c * chunk, min((c + 1) * chunk, n_rows)
-        block = gen_chunk(c, c1 - c0, dim, device)
-        a, b = max(lo, c0), min(hi, c1)
-        part = block[a - c0:b - c0].contiguous()
-        torch.cuda.synchronize()
-        index.add_bulk_device(part.data_ptr(), b - a, dim, first_id=a)
-        del block, part
-    index.flush()
+    index = build_index(vdb, metric, lo, hi, n_rows, dim, device, local_rank)
     index.set_screen(args.screen)
     queries = gen_queries(B, dim, device)
-    mask_t, mask_bits = None, 0
-    if args.filter_mod > 1:
-        keep = (torch.arange(n_rows, device=device) % args.filter_mod == 0)
-        words = torch.zeros(((n_rows + 63) // 64) * 64, dtype=torch.bool, device=device)
-        words[:n_rows] = keep
-        weights = (2 ** torch.arange(8, device=device, dtype=torch.int32)).to(torch.uint8)
-        mask_t = (words.view(-1, 8).to(torch.uint8) * weights).sum(1).to(torch.uint8).contiguous()   # little-endian bit order
-        mask_bits = n_rows
-    searcher = ShardedSearcher(gpu_local_search(index, mask_ptr=mask_t.data_ptr() if mask_t is not None else 0,
-                                                mask_bits=mask_bits, reuse_outputs=True), rank=rank, world=world)
 
-    def step():
-        return searcher.search_batch(queries, k)
+    # ---- c4: the metadata filter, compiled from string metadata to the device bitmask (timed: it is part of an honest C4)
+    mask_t, mask_bits, filt = None, 0, None
+    if args.config == "c4":
+        t1 = time.perf_counter()
+        colors = np.array(PALETTE, dtype=object)[np.arange(n_rows) % 4]
+        store = vdb.VectorStore.with_index(index)
+        store.attach_bulk_metadata(n_rows, {"color": colors})        # ids 0..n-1 <-> rows; the vectors are already in the index
+        t2 = time.perf_counter()
+        mask_np, mask_bits = store.compile_filter(vdb.MetadataFilter.Eq("color", PALETTE[0]))
+        t3 = time.perf_counter()
+        mask_t = torch.from_numpy(mask_np.view(np.int64)).to(device)
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        filt = {"filter": f'eq color="{PALETTE[0]}" (string metadata, 4 values, 25 % selectivity)', "mask_bits": int(mask_bits),
+                "rows_selected": int(np.unpackbits(mask_np.view(np.uint8)).sum()),
+                "metadata_attach_ms": round(1e3 * (t2 - t1), 2), "compile_filter_ms": round(1e3 * (t3 - t2), 3),
+                "mask_upload_ms": round(1e3 * (t4 - t3), 3)}
+
+    # ---- the search path: N = 1 the plain device call; N > 1 the C-ABI shard group (RCCL) or, for rehearsals, its mirror
+    mptr = mask_t.data_ptr() if mask_t is not None else 0
+    group, rccl_ranks = None, None
+    if world > 1 and args.backend == "nccl":
+        group = ShardGroup.from_torch_distributed(local_rank)
+        rccl_ranks = group.world()
+        search = group_search(group, index, mask_ptr=mptr, mask_bits=mask_bits)
+    else:
+        searcher = ShardedSearcher(gpu_local_search(index, mask_ptr=mptr, mask_bits=mask_bits, reuse_outputs=True), rank=rank, world=world)
+        search = searcher.search_batch
+
+    def step(q=None):
+        return search(queries if q is None else q, k)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(fn, n_warm, n_steps):
+        for _ in range(n_warm):
+            o = fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            o = fn()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        return el, o
+
+    elapsed, out = timed(step, args.warmup, args.steps)
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     qps = B * args.steps / elapsed
     stats = index.last_stats()
     out = tuple(t.clone() for t in out)          # the search reuses its output tensors; keep this step's results
 
     # ---- roofline of the dominant kernel, HIP events on its launch stream (vdb_flat_set_profile).
-    # Default path: the bf16 screening kernel streams the f32 rows once -> bound by HBM; algorithmic bytes per
-    # launch = 4*N*d + 4*B*d.  The f32 MFMA tier (set_screen(0)) is measured beside it in the same
-    # run: bound by the f32-input MFMA peak, algorithmic FLOPs 2*B*N*d.
-    def kernel_ms_of(n_iter):
+    def kernel_ms_of(ix, fn, n_iter, rows_local):
         # average duration of ONE launch of the dominant kernel (a batch above 256 queries takes several passes, and
         # the counter sums their launches; rows_scanned / shard rows = launches of that search)
-        index.set_profile(True)
+        ix.set_profile(True)
         ns = []
         for _ in range(n_iter):
-            step()
-            st_ = index.last_stats()
-            ns.append(st_["fused_kernel_ns"] / max(1, round(st_["rows_scanned"] / max(hi - lo, 1))))
-        index.set_profile(False)
+            fn()
+            st_ = ix.last_stats()
+            ns.append(st_["fused_kernel_ns"] / max(1, round(st_["rows_scanned"] / max(rows_local, 1))))
+        ix.set_profile(False)
         return float(np.mean(ns)) / 1e6
 
     n_prof = max(3, min(args.steps, 10))
-    kern_ms = kernel_ms_of(n_prof)
     local_rows = hi - lo
+    kern_ms = kernel_ms_of(index, step, n_prof, local_rows)
     b_launch = min(B, 256)                                      # queries of one launch (a pass handles up to 256)
     alg_flops = 2.0 * b_launch * local_rows * dim               # 2*B*N*d per launch
-    alg_bytes = 4.0 * local_rows * dim + 4.0 * b_launch * dim
+    alg_bytes = 4.0 * local_rows * dim + 4.0 * b_launch * dim   #              4*N*d + 4*B*d per launch
     screened = bool(stats.get("bf16_screen"))
-    traffic = None
+    traffic, traffic_src = None, None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tp) and world == 1 and n_rows == N_ROWS:
+    if os.path.exists(tp) and world == 1 and args.config == "c2" and n_rows == CONFIGS["c2"]["rows"] and dim == 768:
         try:
             tj = json.load(open(tp))
-            traffic = tj.get("hbm_bytes_per_launch_bf16_screen" if screened else "hbm_bytes_per_launch")
+            key = "hbm_bytes_per_launch_bf16_screen" if screened else "hbm_bytes_per_launch"
+            traffic = tj.get(key)
+            traffic_src = (tj.get(key + "_detail") or {}).get("source")
         except Exception:
             traffic = None
-    achieved_tf = alg_flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-    achieved_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    if screened:
-        roofline = {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(achieved_gbs / PEAK_HBM_GBS, 4), "traffic": traffic,
-                    "kernel": "fused_bf16p_kernel<false> (8 waves, 256 rows x 256 queries, f32 rows by LDS-DMA into a 3-image "
-                              "ring, one mid-stage barrier per K stage, bf16 MFMA 32x32x16 scores, threshold filter)",
-                    "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                    "algorithmic_flops_per_launch": alg_flops,
-                    "bf16_mfma_tflops": round(achieved_tf, 1)}
-    else:
-        roofline = {"bound": "mfma", "achieved": round(achieved_tf, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "kernel": "fused_score_filter_dma3_kernel (8 waves, 128 rows x 256 queries, 3-image LDS-DMA ring)", "kernel_ms": round(kern_ms, 4),
-                    "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
-                    "hbm_frac_algorithmic": round(achieved_gbs / PEAK_HBM_GBS, 4) if kern_ms > 0 else None}
-    # the f32 MFMA tier on the same index and queries (only when the default path screened)
+
+    def roofline_of(kms, screened_):
+        tf = alg_flops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        gbs = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        axes = {
+            "hbm": {"achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "algorithmic_bytes_per_launch": alg_bytes},
+            "f32_mfma": {"achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                         "algorithmic_flops_per_launch": alg_flops},
+        }
+        if screened_:
+            axes["f32_mfma"]["note"] = ("NOT the binding axis of this kernel: its contraction runs on the bf16 matrix cores, so the algorithmic "
+                                        "f32 FLOP rate exceeds the f32-MFMA peak (frac > 1); the f32-MFMA-bound path of SURVEY 8(d) is "
+                                        "reported in f32_exact_tier")
+            axes["bf16_mfma"] = {"achieved": round(tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_MFMA_TFLOPS, 4)}
+            b = axes["hbm"]
+            r = {"bound": "hbm", "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"],
+                 "kernel": "fused_bf16p_kernel (8 waves, 256 rows x 256 queries, f32 rows by LDS-DMA into a 3-image ring, one mid-stage "
+                           "barrier per K stage, bf16 MFMA 32x32x16 scores, threshold filter"
+                           + ("; Dot / Euclid instance with per-row error margins)" if metric != 1 else ")")}
+        else:
+            b = axes["f32_mfma"]
+            r = {"bound": "mfma", "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"],
+                 "kernel": "fused_score_filter_dma3_kernel (8 waves, 128 rows x 256 queries, f32-input MFMA 32x32x2, 3-image LDS-DMA ring)"}
+        r.update({"binding_axis": "hbm" if screened_ else "f32_mfma", "axes": axes, "kernel_ms": round(kms, 4)})
+        return r
+
+    roofline = roofline_of(kern_ms, screened)
+    roofline["traffic"] = traffic
+    roofline["traffic_source"] = traffic_src
+
+    # ---- the f32-exact tier: the same index and queries with every score on the f32-input MFMA (SURVEY 8(d)'s f32 axis)
     f32_tier = None
     if screened and not args.no_f32_tier:
         index.set_screen(0)
-        for _ in range(2):
-            step()
-        barrier()
-        t1 = time.perf_counter()
         n_f32 = max(3, min(args.steps, 10))
-        for _ in range(n_f32):
-            out_f32 = step()
-        barrier()
-        el = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=device)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            el = float(t.item())
-        k32 = kernel_ms_of(3)
-        tf32 = alg_flops / (k32 * 1e-3) / 1e12 if k32 > 0 else 0.0
+        el, out_f32 = timed(step, 2, n_f32)
+        k32 = kernel_ms_of(index, step, 3, local_rows)
         same = bool(torch.equal(out_f32[0], out[0]) and torch.equal(out_f32[1].view(torch.int32), out[1].view(torch.int32)))
+        rf = roofline_of(k32, False)
         f32_tier = {"value": round(B * n_f32 / el, 2), "unit": "queries/s", "ms_per_step": round(1e3 * el / n_f32, 4),
-                    "results_identical_to_default_path": same,
-                    "roofline": {"bound": "mfma", "achieved": round(tf32, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": round(tf32 / PEAK_F32_MFMA_TFLOPS, 4), "kernel_ms": round(k32, 4),
-                                 "kernel": "fused_score_filter_dma3_kernel (f32-input MFMA 32x32x2, 3-image LDS-DMA ring)"}}
+                    "dtype": "f32 (f32-input MFMA scores, exact f32 re-rank)", "results_identical_to_default_path": same,
+                    "roofline": rf}
         index.set_screen(1)
+
+    # ---- the harder distribution of SURVEY 8(d): unit-normalised Gaussian rows, Gaussian queries, same size
+    gauss = None
+    if world == 1 and DATA == "uniform" and args.config == "c2" and not args.no_gauss:
+        gidx = build_index(vdb, metric, 0, n_rows, n_rows, dim, device, local_rank, data="gauss")
+        gq = gen_queries(B, dim, device, data="gauss")
+        gsearch = gpu_local_search(gidx, reuse_outputs=True)
+        gel, gout = timed(lambda: gsearch(gq, k), args.warmup, args.steps)
+        gst = gidx.last_stats()
+        gk = kernel_ms_of(gidx, lambda: gsearch(gq, k), 3, n_rows)
+        gauss = {"value": round(B * args.steps / gel, 2), "unit": "queries/s", "ms_per_step": round(1e3 * gel / args.steps, 4),
+                 "kernel_ms": round(gk, 4), "hbm_frac": round(alg_bytes / (gk * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if gk > 0 else None,
+                 "path_stats": {x: gst[x] for x in ("uncertified", "rethreshold_queries", "f32_tier_queries", "exact_queries", "pool_overflows")},
+                 "data": "unit-normalised Gaussian rows, Gaussian queries (seeded)"}
+        if not args.no_cpu:
+            import oracle
+            grows = host_rows(n_rows, dim, device, data="gauss")
+            gi, gd = gout[0].cpu().numpy().astype(np.uint64), gout[1].cpu().numpy()
+            ok = True
+            for b in (0, B - 1):
+                oi, od = oracle.flat_search(metric, grows, gq[b].cpu().numpy(), k)
+                ok &= bool(np.array_equal(oi, gi[b, :len(oi)]) and np.array_equal(od.view(np.uint32), gd[b, :len(od)].view(np.uint32)))
+            gauss["ids_and_distances_bit_identical_to_oracle"] = ok
+            gauss["queries_checked"] = 2
+            del grows
+        del gidx
 
     # ---- the host-pointer entry point (vdb_flat_search_batch): queries cross PCIe in, results out, per batch.
     # Reported beside the headline, never as `value`.
     host_io = None
-    if world == 1 and not args.no_cpu and args.filter_mod <= 1:
+    if world == 1 and not args.no_cpu and mask_t is None:
         q_pin = queries.cpu().numpy()
         index.search_batch_arrays(q_pin, k)
         t1 = time.perf_counter()
@@ -257,26 +347,23 @@ def main():
                    "note": "host numpy arrays in and out (H2D of the queries, D2H of ids/distances/counts inside the step)"}
 
     # ---- cpu_baseline (rank 0, N=1 only): the oracle restatement of the reference, 1 core, bounded sample
-    cpu = None
-    recall = None
-    parity_n = None
-    if rank == 0 and not args.no_cpu:
+    cpu, recall, parity_n = None, None, None
+    if rank == 0 and not args.no_cpu and n_rows * dim <= 2_000_000_000:
         import oracle
         ids_g = out[0].cpu().numpy().astype(np.uint64)
         dist_g = out[1].cpu().numpy()
-        rows_host = np.empty((n_rows, dim), dtype=np.float32)
-        for c in range((n_rows + chunk - 1) // chunk):
-            c0, c1 = c * chunk, min((c + 1) * chunk, n_rows)
-            rows_host[c0:c1] = gen_chunk(c, c1 - c0, dim, device).cpu().numpy()
+        rows_host = host_rows(n_rows, dim, device)
         q_host = queries.cpu().numpy()
-        live_host = (np.arange(n_rows) % args.filter_mod == 0).astype(np.uint8) if args.filter_mod > 1 else None
+        live_host = None
+        if mask_t is not None:
+            live_host = np.unpackbits(mask_t.cpu().numpy().view(np.uint8), bitorder="little")[:n_rows].astype(np.uint8)
         oracle.lib()
         # N = 1: the timed CPU baseline (about cpu-seconds of whole queries); N > 1: two queries, parity only
         budget = args.cpu_seconds if world == 1 else 0.0
         done, t_cpu, recs, exact = 0, 0.0, [], True
         while done < B and (done < 2 or t_cpu < budget):
             t1 = time.perf_counter()
-            oi, od = oracle.flat_search(args.metric, rows_host, q_host[done], k, live=live_host)
+            oi, od = oracle.flat_search(metric, rows_host, q_host[done], k, live=live_host)
             t_cpu += time.perf_counter() - t1
             recs.append(oracle.recall(oi, ids_g[done, :k]))
             exact &= bool(np.array_equal(oi, ids_g[done, :len(oi)]) and np.array_equal(od, dist_g[done, :len(od)]))
@@ -294,8 +381,7 @@ def main():
             nthr = int(min(16, os.cpu_count() or 1, B))
             t1 = time.perf_counter()
             with concurrent.futures.ThreadPoolExecutor(nthr) as ex:
-                list(ex.map(lambda b: oracle.flat_search(args.metric, rows_host, q_host[b], k, live=live_host),
-                            range(nthr)))
+                list(ex.map(lambda b: oracle.flat_search(metric, rows_host, q_host[b], k, live=live_host), range(nthr)))
             t_mt = time.perf_counter() - t1
             cpu["all_cores_row"] = {"value": round(nthr / t_mt, 3), "unit": "queries/s", "cores": nthr,
                                     "sample": f"{nthr} queries, one per thread, {t_mt:.1f} s"}
@@ -303,33 +389,44 @@ def main():
             parity_n = {"queries_checked_against_oracle": done, "ids_and_distances_bit_identical": exact}
 
     if rank == 0:
+        mname = ["euclidean", "cosine", "dot"][metric]
         line = {
-            "metric": "QPS, FlatIndex brute-force kNN 1Mx768 f32 cosine batch=256 k=10 (recall@10 vs reference algorithm)",
+            "metric": f"QPS, FlatIndex brute-force kNN {n_rows}x{dim} f32 {mname} batch={B} k={k} (recall@{k} vs reference algorithm)"
+                      if args.config != "c2" or args.rows else
+                      "QPS, FlatIndex brute-force kNN 1Mx768 f32 cosine batch=256 k=10 (recall@10 vs reference algorithm)",
             "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic" if DATA == "uniform" else "synthetic (unit-normalised Gaussian rows)",
-            "config": {"workload": "FlatIndex 1M x 768 f32, cosine, batch=256 queries, k=10 (BASELINE configs[1])",
-                       "n_rows": n_rows, "dim": dim, "batch": B, "k": k,
-                       "distance": ["euclidean", "cosine", "dot"][args.metric],
-                       "sharding": f"rows/{world}" if world > 1 else "single GPU",
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None,
+            "dtype": ("f32 results (exact f32 re-rank in the reference's operation order); candidates RANKED by bf16-MFMA screening under a tested error bound"
+                      if screened else "f32 (f32-input MFMA scores, exact f32 re-rank)"),
+            "data": "synthetic" if DATA == "uniform" else "synthetic (unit-normalised Gaussian rows)",
+            "config": {"workload": cfg["workload"], "name": args.config,
+                       "n_rows": n_rows, "rows_per_gpu": local_rows, "dim": dim, "batch": B, "k": k, "distance": mname,
+                       "sharding": f"rows/{world}, exchange = RCCL all-gather + merge behind the C ABI (vdb_flat_search_batch_sharded)"
+                                   if group is not None else (f"rows/{world} ({args.backend} mirror of the call pattern)" if world > 1 else "single GPU"),
                        "inputs": "queries and outputs resident in HBM",
                        "arithmetic": ("rows, queries and every reported distance are f32 (exact re-rank in the reference's operation "
-                                      "order, bit-identical to the f32 oracle); candidates are RANKED by bf16-MFMA scores under a "
-                                      "proven error bound, uncertified queries go to the f32-MFMA tier") if screened else
+                                      "order, bit-identical to the f32 oracle); candidates are RANKED by bf16-MFMA scores under an error "
+                                      "bound that tests/test_gpu_certificate.py checks pair by pair on adversarial data; uncertified "
+                                      "queries go to a re-threshold pass, the f32-MFMA tier, then an exact scan") if screened else
                                      "f32 throughout (f32-input MFMA scores, exact f32 re-rank)",
-                       "filter": f"id % {args.filter_mod} == 0 (device bitmask)" if args.filter_mod > 1 else None},
-            "recall_at_10": recall,
+                       "filter": filt},
+            "rccl_ranks": rccl_ranks,
+            "recall_at_k": recall,
             "path_stats": stats,
             "roofline": roofline,
-            "f32_mfma_tier": f32_tier,
+            "f32_exact_tier": f32_tier,
+            "gauss_dataset": gauss,
             "pcie_inclusive": host_io,
             "cpu_baseline": cpu,
         }
+        if args.config == "c2":
+            line["recall_at_10"] = recall
         if parity_n is not None:
             line["parity"] = parity_n
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
+        del group
         torch.distributed.destroy_process_group()
 
 

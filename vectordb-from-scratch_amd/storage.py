@@ -76,6 +76,48 @@ class BatchInsertItem:                               # storage.rs:74-79
     metadata: Metadata = field(default_factory=Metadata)
 
 
+class _Column:
+    """One metadata field as a dictionary-encoded column over internal ids: codes[internal] = index into `values`
+    (-1: the row has no such field).  What `HashMap<usize, Metadata>` (storage.rs:90) holds per row, transposed so that a
+    filter over a million rows is a few numpy passes instead of a million dict lookups."""
+
+    def __init__(self):
+        self.codes = np.full(1024, -1, dtype=np.int32)
+        self.values, self.code_of = [], {}
+
+    def _grow(self, n):
+        if n > self.codes.size:
+            new = np.full(max(n, 2 * self.codes.size), -1, dtype=np.int32)
+            new[:self.codes.size] = self.codes
+            self.codes = new
+
+    def code(self, value, create=False):
+        c = self.code_of.get(value)
+        if c is None and create:
+            c = self.code_of[value] = len(self.values)
+            self.values.append(value)
+        return c
+
+    def set(self, internal, value):
+        self._grow(internal + 1)
+        self.codes[internal] = self.code(value, create=True)
+
+    def set_range(self, start, values):
+        """values: a sequence of n strings (or None for 'no such field') for internal ids start .. start+n-1."""
+        vals = np.asarray(values, dtype=object)
+        self._grow(start + vals.size)
+        uniq, inv = np.unique(np.where(vals == None, "", vals).astype(str), return_inverse=True)   # noqa: E711
+        lut = np.array([self.code(u, create=True) for u in uniq], dtype=np.int32)
+        codes = lut[inv]
+        if (vals == None).any():                                                                  # noqa: E711
+            codes = np.where(vals == None, -1, codes)                                             # noqa: E711
+        self.codes[start:start + vals.size] = codes
+
+    def view(self, n):
+        self._grow(n)
+        return self.codes[:n]
+
+
 class VectorStore:
     """VectorStore<I: Index>  (storage.rs:83-95).  `VectorStore(metric)` builds the GPU flat index
     where the reference's `VectorStore::new` builds a FlatIndex (storage.rs:99-101)."""
@@ -90,6 +132,11 @@ class VectorStore:
         self._metadata = {}
         self._next_id = 0
         self._dimension = None
+        # filter compilation: the metadata as dictionary-encoded columns + a presence bitmap, kept in
+        # step with every insert / upsert / delete
+        self._cols = {}
+        self._present = np.zeros(1024, dtype=bool)
+        self._bulk = []                                  # attach_bulk_metadata ranges: (first internal id, n, ids or None)
 
     @classmethod
     def with_index(cls, index):                      # storage.rs:118-127
@@ -118,6 +165,11 @@ class VectorStore:
         self._id_to_internal[id] = internal
         self._internal_to_id[internal] = id
         self._metadata[internal] = metadata
+        self._mark_present(internal, True)
+        for key, value in metadata.fields().items():
+            self._cols.setdefault(key, _Column()).set(internal, value)
+        if old is not None:
+            self._mark_present(old, False)
 
     def insert_batch(self, items):                   # storage.rs:293-298
         for it in items:
@@ -133,6 +185,7 @@ class VectorStore:
         self._internal_to_id.pop(internal, None)
         self._metadata.pop(internal, None)
         self._index.remove(internal)
+        self._mark_present(internal, False)
         return v
 
     # ---- reads
@@ -142,6 +195,10 @@ class VectorStore:
 
     def get_metadata(self, id):                      # storage.rs:201-204
         internal = self._id_to_internal.get(id)
+        if internal is None and self._bulk and str(id).isdigit() and self._bulk_id(int(id)) == str(id):
+            internal = int(id)
+            return Metadata({k: c.values[c.codes[internal]] for k, c in self._cols.items()
+                             if internal < c.codes.size and c.codes[internal] >= 0})
         return None if internal is None else self._metadata.get(internal)
 
     def len(self):
@@ -165,6 +222,42 @@ class VectorStore:
     def list_ids(self):
         return list(self._id_to_internal)
 
+    def _mark_present(self, internal, on):
+        if internal >= self._present.size:
+            new = np.zeros(max(internal + 1, 2 * self._present.size), dtype=bool)
+            new[:self._present.size] = self._present
+            self._present = new
+        self._present[internal] = on
+
+    def attach_bulk_metadata(self, n, columns, ids=None):
+        """Register n rows that are ALREADY in the index under the next n internal ids (a bulk device load, a mapped
+        vector file: persistence/mmap.rs has no id or metadata column) together with their metadata columns
+        {field: sequence of n strings / None}.  String ids default to the decimal internal id.  The per-row
+        `Metadata` objects of the reference (storage.rs:90) are materialised only when asked for (get_metadata)."""
+        n = int(n)
+        start = self._next_id
+        if ids is not None and len(ids) != n:
+            raise ValueError("ids must have n entries")
+        for key, values in columns.items():
+            if len(values) != n:
+                raise ValueError(f"column {key!r} must have n entries")
+            self._cols.setdefault(key, _Column()).set_range(start, values)
+        self._mark_present(start + n - 1, False)                 # grow once
+        self._present[start:start + n] = True
+        self._bulk.append((start, n, None if ids is None else list(ids)))
+        self._next_id += n
+        if self._dimension is None and hasattr(self._index, "dim"):
+            self._dimension = self._index.dim() or None
+        return start
+
+    def _bulk_id(self, internal):
+        for start, n, ids in self._bulk:
+            if start <= internal < start + n:
+                if not self._present[internal]:
+                    return None
+                return str(internal) if ids is None else ids[internal - start]
+        return None
+
     def _check_dim(self, query):
         if self._dimension is not None and query.dimension() != self._dimension:
             raise DimensionMismatch(self._dimension, query.dimension())
@@ -173,6 +266,8 @@ class VectorStore:
         out = []
         for internal, dist in index_results:         # storage.rs:234-242
             sid = self._internal_to_id.get(internal)
+            if sid is None and self._bulk:
+                sid = self._bulk_id(internal)
             if sid is not None:
                 out.append(SearchResult(sid, float(dist)))
         return out
@@ -223,13 +318,40 @@ class VectorStore:
 
     # ---- BASELINE config 4: the filter compiled to a device bitmask applied BEFORE top-k.
     # The reference's post-filter result is always a prefix of this one.
+    def _eval_filter(self, flt, n):
+        """MetadataFilter::matches (storage.rs:60-71) for ALL internal ids below n at once: a bool array."""
+        if flt.op in ("eq", "ne", "exists"):
+            col = self._cols.get(flt.field)
+            if col is None:                                       # nobody has the field: Eq / Exists never match, Ne always does
+                return np.full(n, flt.op == "ne", dtype=bool)
+            codes = col.view(n)
+            if flt.op == "exists":
+                return codes >= 0
+            c = col.code(flt.value)
+            if flt.op == "eq":
+                return (codes == c) if c is not None else np.zeros(n, dtype=bool)
+            return (codes != c) if c is not None else np.ones(n, dtype=bool)      # Ne: a missing field matches (storage.rs:65)
+        if flt.op in ("and", "or"):
+            acc = np.full(n, flt.op == "and", dtype=bool)          # all([]) is true, any([]) is false, like Rust's iterators
+            for f in flt.filters:
+                m = self._eval_filter(f, n)
+                acc = (acc & m) if flt.op == "and" else (acc | m)
+            return acc
+        raise ValueError(flt.op)
+
     def compile_filter(self, flt):
+        """The filter as the id bitmask the device applies before top-k (bit i of word i>>6 = internal id i eligible).
+        Vectorised over the dictionary-encoded metadata columns: eq / ne / exists are one comparison of an int32 column,
+        and / or combine bool arrays, the presence bitmap removes deleted and superseded ids, np.packbits packs."""
         bits = max(self._next_id, 1)
-        mask = np.zeros((bits + 63) // 64, dtype=np.uint64)
-        for internal, meta in self._metadata.items():
-            if flt.matches(meta):
-                mask[internal >> 6] |= np.uint64(1) << np.uint64(internal & 63)
-        return mask, bits
+        m = self._eval_filter(flt, bits)
+        pres = self._present[:bits] if self._present.size >= bits else np.concatenate([self._present, np.zeros(bits - self._present.size, dtype=bool)])
+        m = m & pres
+        words = (bits + 63) // 64
+        packed = np.zeros(words * 8, dtype=np.uint8)
+        pb = np.packbits(m, bitorder="little")
+        packed[:pb.size] = pb
+        return packed.view(np.uint64), bits
 
     def search_batch_prefiltered(self, queries, flt):
         if self.is_empty():
