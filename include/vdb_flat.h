@@ -167,6 +167,22 @@ int vdb_flat_search_batch_device_begin(vdb_flat_index *h, const float *d_queries
                                        float *d_out_dists, uint32_t *d_out_counts, int32_t *d_code, void *stream);
 int vdb_flat_search_batch_device_finish(vdb_flat_index *h, int *changed);
 
+/*
+ * The device-resident search ASYNCHRONOUSLY, two batches in flight per handle (no reference counterpart: the reference's
+ * batch loop, src/storage.rs:302-310, is synchronous; this is what a server that keeps the GPU busy calls instead).
+ * _submit runs every check and enqueues the first tier on `stream` (NULL = a stream of the context it picked) and
+ * returns a ticket WITHOUT waiting; _wait(ticket) waits for that search, runs its fallback tiers where needed and reports
+ * the errors a plain vdb_flat_search_batch_device call would.  While batch i's HBM-bound pass runs, batch i+1's query
+ * preparation and the host's turnaround are hidden behind it.  Rules: at most two tickets outstanding per handle (a third
+ * submit fails); every ticket must be waited for exactly once; outputs are complete when _wait returns; add / remove /
+ * flush and the host-pointer entry points are refused while a ticket is outstanding (the caller's read lock spans
+ * submit .. wait, routes.rs:244,:342); a synchronous vdb_flat_search_batch_device call may run beside ONE outstanding ticket.
+ */
+int vdb_flat_search_batch_device_submit(vdb_flat_index *h, const float *d_queries, size_t nq, size_t dim, size_t k,
+                                        const uint64_t *d_id_mask, size_t mask_bits, uint64_t *d_out_ids,
+                                        float *d_out_dists, uint32_t *d_out_counts, void *stream, int *ticket);
+int vdb_flat_search_batch_device_wait(vdb_flat_index *h, int ticket);
+
 /* The same merge reading the all-gathered exchange buffer in place.  Each part is `words_per_part` int32
  * words (even): ids int64[nq*k] | dists f32[nq*k] | counts i32[nq] | status i32 | pad.  *d_out_status (may be
  * NULL) receives the maximum status word over the parts, so one host read tells whether any shard failed. */

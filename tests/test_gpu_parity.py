@@ -421,3 +421,69 @@ def test_shape_boundaries(vdb, n, d, nq, k, metric):
     st = ix.last_stats()
     assert st["pool_overflows"] == 0, st
     assert (st["rows_scanned"] > 0) == (n > 16384), st
+
+
+def test_two_searches_in_flight_submit_wait(vdb):
+    """vdb_flat_search_batch_device_submit / _wait: two batches in flight on two contexts and streams.  Results equal the
+    synchronous call's bit for bit whatever the interleaving; a third submit, a mutation or a host-pointer search while a
+    ticket is outstanding is refused; errors surface at wait like at the synchronous call; the handle stays usable."""
+    import torch
+    rng = np.random.default_rng(77)
+    n, d, B, k = 120_000, 64, 200, 10
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    ix = make_index(vdb, 1, rows)
+    qs = [torch.from_numpy(rng.standard_normal((B, d)).astype(np.float32)).to(dev) for _ in range(5)]
+    outs = [(torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+             torch.empty((B,), dtype=torch.int32, device=dev)) for _ in range(5)]
+    ref = []
+    for q in qs:                                                # synchronous reference
+        o = (torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+             torch.empty((B,), dtype=torch.int32, device=dev))
+        ix.search_batch_device(q.data_ptr(), B, d, k, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+        ref.append(tuple(t.clone() for t in o))
+    torch.cuda.synchronize()
+
+    def submit(i):
+        return ix.search_batch_device_submit(qs[i].data_ptr(), B, d, k, outs[i][0].data_ptr(), outs[i][1].data_ptr(), outs[i][2].data_ptr())
+
+    t0 = submit(0)
+    for i in range(1, 5):                                       # keep two in flight
+        t1 = submit(i)
+        with pytest.raises(vdb.VectorDbError):
+            submit(0)                                           # a third ticket is refused
+        with pytest.raises(vdb.VectorDbError):
+            ix.add(10**7, vdb.Vector(rows[0]))                  # the row store must not change under a search in flight
+        with pytest.raises(vdb.VectorDbError):
+            ix.search_batch_arrays(rows[:2], 3)                 # host-pointer entry: refused as well
+        ix.search_batch_device_wait(t0)
+        t0 = t1
+    ix.search_batch_device_wait(t0)
+    with pytest.raises(vdb.VectorDbError):
+        ix.search_batch_device_wait(t0)                         # a ticket is waited for exactly once
+    torch.cuda.synchronize()
+    for i in range(5):
+        for a, b in zip(outs[i], ref[i]):
+            assert torch.equal(a, b), i
+    st = ix.last_stats()
+    assert st["bf16_screen"] == 1 and st["mfma_queries"] == B
+    # a synchronous device search may run beside ONE outstanding ticket
+    t = submit(1)
+    o = (torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+         torch.empty((B,), dtype=torch.int32, device=dev))
+    ix.search_batch_device(qs[2].data_ptr(), B, d, k, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+    ix.search_batch_device_wait(t)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(o, ref[2])) and all(torch.equal(a, b) for a, b in zip(outs[1], ref[1]))
+    # an error found on the device (zero-norm query under Cosine) comes back from wait; the slot is free again afterwards
+    qz = qs[0].clone()
+    qz[7] = 0.0
+    t = ix.search_batch_device_submit(qz.data_ptr(), B, d, k, outs[0][0].data_ptr(), outs[0][1].data_ptr(), outs[0][2].data_ptr())
+    with pytest.raises(vdb.InvalidVector):
+        ix.search_batch_device_wait(t)
+    t = submit(3)
+    ix.search_batch_device_wait(t)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(outs[3], ref[3]))
+    ix.add(10**7, vdb.Vector(rows[0]))                          # mutations work again
+    assert ix.len() == n + 1

@@ -133,6 +133,10 @@ struct SelectParams {
     uint64_t* out_last;                                // may be null: largest selected key per query (unchanged if none)
 };
 void launch_select(const SelectParams& p, uint32_t nq, hipStream_t s);
+// The screening tier's THRESHOLD select: only the score of the kk-th smallest of n_fixed <= 4096 keys per query is wanted
+// (out_thr, with the shift_g / shift_m_bits adjustment) -- no sorted list.  A 256-thread workgroup keeps the keys' score
+// words in registers and finds the value with four 8-bit radix passes: ~5 us against the general kernel's ~15.
+void launch_thr_select(const SelectParams& p, uint32_t nq, hipStream_t s);
 
 // ---------------------------------------------------------------- fused MFMA score + threshold filter
 struct FusedParams {

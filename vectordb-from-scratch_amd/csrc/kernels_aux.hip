@@ -566,6 +566,78 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
         }
     }
 }
+constexpr uint32_t TS_THREADS = 256, TS_PER = 16;                 // up to 4096 keys per query
+__global__ __launch_bounds__(TS_THREADS) void thr_select_kernel(SelectParams p) {
+    __shared__ uint32_t sHist[256];
+    __shared__ uint32_t sDigit, sRemain, sValid;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const uint64_t* keys = p.keys + (size_t)q * p.stride;
+    const uint32_t n = p.n_fixed;
+    // the ORDER of two keys with the same score word does not matter for the VALUE of the kk-th smallest score, so only the
+    // high words take part (an empty slot, ~0, sorts last)
+    uint32_t v[TS_PER];
+    uint32_t myvalid = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < TS_PER; ++u) {
+        const uint32_t i = u * TS_THREADS + tid;
+        uint32_t hi = 0xffffffffu;
+        if (i < n) { const uint64_t key = keys[i]; if (key != EMPTY_KEY) { hi = (uint32_t)(key >> 32); ++myvalid; } }
+        v[u] = hi;
+    }
+    if (tid == 0) sValid = 0;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) myvalid += __shfl_xor(myvalid, o);
+    if (lane == 0 && myvalid) atomicAdd(&sValid, myvalid);
+    __syncthreads();
+    const uint32_t nvalid = sValid;
+    float t = __uint_as_float(0x7f800000u);                        // fewer than kk valid keys: +inf, everything passes
+    if (nvalid >= p.kk && p.kk > 0) {
+        uint32_t prefix = 0, remain = p.kk;
+        for (int b = 3; b >= 0; --b) {
+            sHist[tid] = 0;
+            __syncthreads();
+            const int shift = 8 * b;
+#pragma unroll
+            for (uint32_t u = 0; u < TS_PER; ++u) {
+                const bool in = v[u] != 0xffffffffu && (b == 3 || (v[u] >> (shift + 8)) == prefix);
+                if (in) atomicAdd(&sHist[(v[u] >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const uint32_t c0 = sHist[4 * lane], c1 = sHist[4 * lane + 1], c2 = sHist[4 * lane + 2], c3 = sHist[4 * lane + 3];
+                const uint32_t sum = c0 + c1 + c2 + c3;
+                uint32_t incl = sum;
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(incl, o); if ((int)lane >= o) incl += x; }
+                const unsigned long long hit = __ballot(incl >= remain);
+                const int first = __ffsll((long long)hit) - 1;
+                if ((int)lane == first) {
+                    uint32_t r = remain - (incl - sum), d = 0;
+                    if (r > c0) { r -= c0; d = 1; if (r > c1) { r -= c1; d = 2; if (r > c2) { r -= c2; d = 3; } } }
+                    sDigit = 4 * lane + d;
+                    sRemain = r;
+                }
+            }
+            __syncthreads();
+            prefix = (prefix << 8) | sDigit;
+            remain = sRemain;
+            __syncthreads();
+        }
+        t = ordered_to_f32(prefix);
+    }
+    if (tid == 0) {
+        if (p.shift_g) {
+            const uint32_t mb = *p.shift_m_bits;
+            if (mb) t = fmaf(-p.shift_g[q], __uint_as_float(~mb), t);
+        }
+        p.out_thr[q] = t;
+    }
+}
+void launch_thr_select(const SelectParams& p, uint32_t nq, hipStream_t s) {
+    if (!nq) return;
+    if (p.n_fixed > TS_THREADS * TS_PER || p.n_sub || p.counts || p.lo_excl || !p.out_thr) { launch_select(p, nq, s); return; }
+    hipLaunchKernelGGL(thr_select_kernel, dim3(nq), dim3(TS_THREADS), 0, s, p);
+}
+
 void launch_select(const SelectParams& p, uint32_t nq, hipStream_t s) {
     if (!nq) return;
     hipLaunchKernelGGL(select_kernel, dim3(nq), dim3(SEL_THREADS), (SEL_LDS_KEYS + SEL_MAX_KK) * sizeof(uint64_t), s, p);

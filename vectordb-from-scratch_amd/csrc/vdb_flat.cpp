@@ -107,6 +107,42 @@ constexpr uint32_t MAX_SELECT = 2048;   // select kernel capacity (kk)
 
 }  // namespace
 
+struct Workspace {
+    DevBuf<float> w_qp, w_qnorm, w_thr, w_qin, w_outd, w_qerr, w_qg, w_dbg;
+    uint32_t dbg_nq = 0; bool dbg_lb = false;             // vdb_flat_debug_screen_scores left this many prepared queries in the workspace
+    DevBuf<uint64_t> w_dense, w_samp, w_pool, w_cand, w_exact, w_exsel, w_mask_ids, w_outi;
+    DevBuf<uint32_t> w_cnt, w_rowmask, w_flags, w_outc, w_subcnt, w_depth;
+    DevBuf<uint16_t> w_qb;                                  // bf16 copy of the padded queries (screening tier)
+    // compact block of the queries the screening tier could not certify (re-run by the f32 tier)
+    DevBuf<float> w2_qp, w2_qnorm, w2_thr, w2_outd, w2_qerr, w2_qg;
+    DevBuf<uint64_t> w2_outi, w2_cand;
+    DevBuf<uint16_t> w2_qb;
+    DevBuf<uint32_t> w2_outc, w2_flags, w2_qidx;
+    uint32_t* h_flags = nullptr; size_t h_flags_n = 0;
+    bool status_dirty = true; uint32_t* status_buf = nullptr;   // device status block known to be zero?
+    // a search between its two halves (search_part1 enqueues the first tier, search_part2 reads its flags and runs
+    // the fallback tiers): vdb_flat_search_batch_device_begin / _finish keep the handle locked in between
+    struct SearchCtx {
+        bool pending = false;                               // part 2 still has to run
+        uint32_t nq32 = 0, kp = 0, kp16 = 0;
+        size_t k = 0;
+        hipStream_t s = nullptr;
+        const uint32_t* d_rowmask = nullptr;
+        uint64_t* d_out_ids = nullptr; float* d_out_dists = nullptr; uint32_t* d_out_counts = nullptr;
+        std::chrono::steady_clock::time_point t_entry;
+    } ctx;
+    uint64_t stats[16] = {0};
+    hipStream_t stream = nullptr;                           // this context's own stream (used when the caller passes none)
+    bool busy = false;                                      // submitted, not yet waited for
+    template <class F> void for_each_buffer(F&& f) {
+        f(w_qp); f(w_qnorm); f(w_thr); f(w_qin); f(w_outd); f(w_qerr); f(w_qg); f(w_dbg);
+        f(w_dense); f(w_samp); f(w_pool); f(w_cand); f(w_exact); f(w_exsel); f(w_mask_ids); f(w_outi);
+        f(w_cnt); f(w_rowmask); f(w_flags); f(w_outc); f(w_subcnt); f(w_depth); f(w_qb);
+        f(w2_qp); f(w2_qnorm); f(w2_thr); f(w2_outd); f(w2_qerr); f(w2_qg); f(w2_outi); f(w2_cand); f(w2_qb);
+        f(w2_outc); f(w2_flags); f(w2_qidx);
+    }
+};
+
 // Diagnostic knobs: ablation switches, A/B kernel variants, scaled certificates, sample-size overrides.  Several of them
 // VOID the exact-result guarantee, so they exist only in the diagnostics build (-DVDB_DIAG -> libvdbflat_diag.so,
 // `make diag`), where vdb_flat_create reads them from the environment ONCE into the handle.  In the release library
@@ -155,37 +191,17 @@ struct vdb_flat_index {
     bool zero_valid = false; uint32_t zero_live = 0;
     DevBuf<uint32_t> d_idrank, d_rank2row; bool rank_valid = false;
 
-    // search workspace
-    DevBuf<float> w_qp, w_qnorm, w_thr, w_qin, w_outd, w_qerr, w_qg, w_dbg;
-    uint32_t dbg_nq = 0; bool dbg_lb = false;             // vdb_flat_debug_screen_scores left this many prepared queries in the workspace
-    DevBuf<uint64_t> w_dense, w_samp, w_pool, w_cand, w_exact, w_exsel, w_mask_ids, w_outi;
-    DevBuf<uint32_t> w_cnt, w_rowmask, w_flags, w_outc, w_subcnt, w_depth;
-    DevBuf<uint16_t> w_qb;                                  // bf16 copy of the padded queries (screening tier)
-    // compact block of the queries the screening tier could not certify (re-run by the f32 tier)
-    DevBuf<float> w2_qp, w2_qnorm, w2_thr, w2_outd, w2_qerr, w2_qg;
-    DevBuf<uint64_t> w2_outi, w2_cand;
-    DevBuf<uint16_t> w2_qb;
-    DevBuf<uint32_t> w2_outc, w2_flags, w2_qidx;
-    uint32_t* h_flags = nullptr; size_t h_flags_n = 0;
-    bool status_dirty = true; uint32_t* status_buf = nullptr;   // device status block known to be zero?
+    // search workspace: everything one search in flight owns.  Two of them, so that two batches can be in flight on two
+    // streams (vdb_flat_search_batch_device_submit / _wait); every synchronous entry point uses the first.
+    struct Workspace* cur = nullptr;                        // the context the search code below works in (set under the handle mutex)
+    struct Workspace* wsv = nullptr;                        // [2]
     // mapped host memory for the pair hooks (vdb_internal.h): the kernel reads the pairs and writes the distances in place
     uint32_t* h_pairs = nullptr; float* h_pout = nullptr; size_t h_pairs_cap = 0, h_pout_cap = 0;
     uint32_t pairs_nq = 0;
-    // a search between its two halves (search_part1 enqueues the first tier, search_part2 reads its flags and runs
-    // the fallback tiers): vdb_flat_search_batch_device_begin / _finish keep the handle locked in between
-    struct SearchCtx {
-        bool pending = false;                               // part 2 still has to run
-        uint32_t nq32 = 0, kp = 0, kp16 = 0;
-        size_t k = 0;
-        hipStream_t s = nullptr;
-        const uint32_t* d_rowmask = nullptr;
-        uint64_t* d_out_ids = nullptr; float* d_out_dists = nullptr; uint32_t* d_out_counts = nullptr;
-        std::chrono::steady_clock::time_point t_entry;
-    } ctx;
     bool begin_locked = false;
     hipEvent_t ev_order = nullptr;                          // orders the handle's stream before the null stream (search_batch_device_begin)
     int screen = 1;                                         // 1: bf16 screening tier first (default), 0: f32 MFMA tier only
-    uint64_t stats[16] = {0};
+    uint64_t stats[16] = {0};                               // counters of the last COMPLETED search (copied from its context)
     bool profile = false; hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     uint32_t n_rows() const { return (uint32_t)row_ids.size(); }
@@ -487,26 +503,26 @@ int exact_one(Index* ix, hipStream_t s, uint32_t q, size_t k, const uint32_t* d_
     int rc;
     uint32_t n = ix->n_uploaded;
     if ((rc = ensure_ranks(ix))) return rc;
-    if ((rc = ix->w_exact.ensure(n))) return rc;
-    if ((rc = ix->w_exsel.ensure(MAX_SELECT + 8))) return rc;
-    if ((rc = ix->w_cnt.ensure(4 * SUPER + 16))) return rc;
-    vdb::ExactScanParams ep{ix->d_rows, ix->ld, ix->dim, n, ix->w_qp.p + (size_t)q * ix->ld, ix->w_qnorm.p + q, ix->d_nd,
-                            d_rowmask, ix->ids_monotone ? nullptr : ix->d_idrank.p, ix->metric, ix->w_exact.p,
-                            ix->w_flags.p};
+    if ((rc = ix->cur->w_exact.ensure(n))) return rc;
+    if ((rc = ix->cur->w_exsel.ensure(MAX_SELECT + 8))) return rc;
+    if ((rc = ix->cur->w_cnt.ensure(4 * SUPER + 16))) return rc;
+    vdb::ExactScanParams ep{ix->d_rows, ix->ld, ix->dim, n, ix->cur->w_qp.p + (size_t)q * ix->ld, ix->cur->w_qnorm.p + q, ix->d_nd,
+                            d_rowmask, ix->ids_monotone ? nullptr : ix->d_idrank.p, ix->metric, ix->cur->w_exact.p,
+                            ix->cur->w_flags.p};
     vdb::launch_exact_scan(ep, s);
-    uint32_t* cnt = ix->w_cnt.p + 4 * SUPER;
-    uint64_t* last = ix->w_exsel.p + MAX_SELECT;      // largest key emitted so far (one u64 after the sort area)
+    uint32_t* cnt = ix->cur->w_cnt.p + 4 * SUPER;
+    uint64_t* last = ix->cur->w_exsel.p + MAX_SELECT;      // largest key emitted so far (one u64 after the sort area)
     // k may be as large as the index: emit in chunks of MAX_SELECT, each chunk = the smallest keys
     // strictly above the previous chunk's last key
     for (size_t done = 0; done < k; done += MAX_SELECT) {
         uint32_t kk = (uint32_t)std::min<size_t>(MAX_SELECT, k - done);
         vdb::SelectParams sp{};
-        sp.keys = ix->w_exact.p; sp.stride = 0; sp.counts = nullptr; sp.n_fixed = n; sp.cap = n;
-        sp.kk = kk; sp.out_keys = ix->w_exsel.p; sp.out_stride = MAX_SELECT; sp.out_cnt = cnt;
+        sp.keys = ix->cur->w_exact.p; sp.stride = 0; sp.counts = nullptr; sp.n_fixed = n; sp.cap = n;
+        sp.kk = kk; sp.out_keys = ix->cur->w_exsel.p; sp.out_stride = MAX_SELECT; sp.out_cnt = cnt;
         sp.out_thr = nullptr; sp.ovf = nullptr;
         sp.lo_excl = done ? last : nullptr; sp.out_last = last;
         vdb::launch_select(sp, 1, s);
-        vdb::EmitParams em{ix->w_exsel.p, MAX_SELECT, cnt, ix->ids_monotone ? nullptr : ix->d_rank2row.p,
+        vdb::EmitParams em{ix->cur->w_exsel.p, MAX_SELECT, cnt, ix->ids_monotone ? nullptr : ix->d_rank2row.p,
                            ix->d_row_ids, d_out_ids + done, d_out_dists + done, d_out_count, kk, done ? 1u : 0u};
         vdb::launch_emit(em, s);
     }
@@ -538,16 +554,16 @@ int pass_f32(Index* ix, hipStream_t s, const float* qp, const float* qnorm, floa
     const uint32_t capl = 64;
     // sub-pools in one pass = queries * row ranges * row parts * 2 = 512 * n_cu for every kernel shape
     const size_t pass_subs = 512u * (size_t)ix->n_cu;
-    if ((rc = ix->w_dense.ensure((size_t)SUPER * S))) return rc;
-    if ((rc = ix->w_cand.ensure((size_t)SUPER * kp))) return rc;
+    if ((rc = ix->cur->w_dense.ensure((size_t)SUPER * S))) return rc;
+    if ((rc = ix->cur->w_cand.ensure((size_t)SUPER * kp))) return rc;
     if (!small) {
-        if ((rc = ix->w_samp.ensure((size_t)SUPER * kp))) return rc;
-        if ((rc = ix->w_pool.ensure(pass_subs * capl))) return rc;
-        if ((rc = ix->w_subcnt.ensure(pass_subs))) return rc;
+        if ((rc = ix->cur->w_samp.ensure((size_t)SUPER * kp))) return rc;
+        if ((rc = ix->cur->w_pool.ensure(pass_subs * capl))) return rc;
+        if ((rc = ix->cur->w_subcnt.ensure(pass_subs))) return rc;
     }
-    uint32_t* d_cnt_a = ix->w_cnt.p;               // sample select counts
-    uint32_t* d_cand_cnt = ix->w_cnt.p + 2 * SUPER;
-    if (!ix->stats[8]) { ix->stats[4] = S; ix->stats[5] = kp; }
+    uint32_t* d_cnt_a = ix->cur->w_cnt.p;               // sample select counts
+    uint32_t* d_cand_cnt = ix->cur->w_cnt.p + 2 * SUPER;
+    if (!ix->cur->stats[8]) { ix->cur->stats[4] = S; ix->cur->stats[5] = kp; }
     const float eps = eps_coef(ix);
 
     for (uint32_t q0 = 0; q0 < nq; q0 += SUPER) {
@@ -560,26 +576,26 @@ int pass_f32(Index* ix, hipStream_t s, const float* qp, const float* qnorm, floa
         const float* qp0 = qp + (size_t)q0 * ld;
 
         vdb::DenseParams dp{ix->d_rows, ld, n, qp0, round_up(nb, 32), ix->d_alpha, ix->d_beta, d_rowmask, S,
-                            ix->w_dense.p, S};
+                            ix->cur->w_dense.p, S};
         vdb::launch_dense_scores(dp, s);
 
         vdb::SelectParams sp{};
-        sp.keys = ix->w_dense.p; sp.stride = S; sp.counts = nullptr; sp.n_fixed = S; sp.cap = S; sp.kk = kp;
+        sp.keys = ix->cur->w_dense.p; sp.stride = S; sp.counts = nullptr; sp.n_fixed = S; sp.cap = S; sp.kk = kp;
         sp.out_stride = kp;
         if (small) {
-            sp.out_keys = ix->w_cand.p; sp.out_cnt = d_cand_cnt; sp.out_thr = nullptr; sp.ovf = nullptr;
+            sp.out_keys = ix->cur->w_cand.p; sp.out_cnt = d_cand_cnt; sp.out_thr = nullptr; sp.ovf = nullptr;
             vdb::launch_select(sp, nb, s);
         } else {
             // thresholds: the sample's kp-th score (padding queries were given -inf by query_prep)
-            sp.out_keys = ix->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = thr + q0; sp.ovf = nullptr;
+            sp.out_keys = ix->cur->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = thr + q0; sp.ovf = nullptr;
             vdb::launch_select(sp, nb, s);
             const uint32_t n_wg = std::min<uint32_t>((nqt == 8 ? 1u : 2u) * (uint32_t)ix->n_cu / n_super, (n + 31) / 32);
             const uint32_t n_sub = vdb::fused_subpools_per_query(nqt, n_wg);
             vdb::FusedParams fp{ix->d_rows, ld, n, qp, q0, ix->d_alpha, ix->d_beta, d_rowmask ? d_rowmask : ix->d_live,
-                                thr, ix->w_pool.p - (size_t)q0 * n_sub * capl,
-                                ix->w_subcnt.p - (size_t)q0 * n_sub, capl, n_wg,
+                                thr, ix->cur->w_pool.p - (size_t)q0 * n_sub * capl,
+                                ix->cur->w_subcnt.p - (size_t)q0 * n_sub, capl, n_wg,
                                 ix->kn.fused_ablate};
-            const bool prof = ix->profile && !ix->stats[8];       // with the screening tier on, ITS kernel is the one timed
+            const bool prof = ix->profile && !ix->cur->stats[8];       // with the screening tier on, ITS kernel is the one timed
             if (prof) HIP_TRY(hipEventRecord(ix->ev0, s));
             // 256-query passes: LDS-DMA staging, 3-image ring with the barrier in mid-stage; smaller batches: the
             // register-staged 128/64/32-query shapes.  (Diagnostics build: the 2-image and register-staged A/B variants.)
@@ -596,20 +612,20 @@ int pass_f32(Index* ix, hipStream_t s, const float* qp, const float* qnorm, floa
                 HIP_TRY(hipEventSynchronize(ix->ev1));
                 float ms = 0.f;
                 HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
-                ix->stats[7] += (uint64_t)((double)ms * 1e6);
+                ix->cur->stats[7] += (uint64_t)((double)ms * 1e6);
             }
-            ix->stats[3] += n;
+            ix->cur->stats[3] += n;
             vdb::SelectParams mp{};
-            mp.keys = ix->w_pool.p; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
-            mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl;
-            mp.kk = kp; mp.out_keys = ix->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
+            mp.keys = ix->cur->w_pool.p; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
+            mp.sub_counts = ix->cur->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl;
+            mp.kk = kp; mp.out_keys = ix->cur->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
             mp.out_thr = nullptr; mp.ovf = d_ovf + q0; mp.summary = d_status + 1;
             vdb::launch_select(mp, nb, s);
         }
         vdb::RerankParams rp{};
         rp.rows = ix->d_rows; rp.ld = ld; rp.dim = ix->dim; rp.n_rows = n;
         rp.qp = qp0; rp.qnorm = qnorm + q0; rp.nd = ix->d_nd; rp.row_ids = ix->d_row_ids;
-        rp.rowmask = d_rowmask; rp.cand = ix->w_cand.p; rp.cand_stride = kp; rp.cand_cnt = d_cand_cnt; rp.kp = kp;
+        rp.rowmask = d_rowmask; rp.cand = ix->cur->w_cand.p; rp.cand_stride = kp; rp.cand_cnt = d_cand_cnt; rp.kp = kp;
         rp.metric = ix->metric; rp.k = (uint32_t)k; rp.eps_coef = eps; rp.nd2max_bits = ix->d_scalars;
         rp.out_ids = d_out_ids + (size_t)q0 * k; rp.out_dists = d_out_dists + (size_t)q0 * k;
         rp.out_counts = d_out_counts + q0; rp.out_stride = (uint32_t)k; rp.cert = d_cert + q0; rp.status = d_status;
@@ -622,7 +638,7 @@ int pass_f32(Index* ix, hipStream_t s, const float* qp, const float* qnorm, floa
 // ------------------------------------------------------------------ tier: bf16 screening + certified re-rank
 // Same structure, with the scores of the HBM-bound bf16 kernel (kernels_fused_bf16.hip): group minima of a row
 // sample -> per-query threshold -> one pass over all rows keeping the keys under the threshold -> the kp smallest
-// keys -> exact re-rank, certified with the bf16 error bound.  Queries come from ix->w_qp / w_qb / w_qnorm.
+// keys -> exact re-rank, certified with the bf16 error bound.  Queries come from ix->cur->w_qp / w_qb / w_qnorm.
 int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& pl, const uint32_t* d_rowmask,
               uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, uint32_t* d_cert, uint32_t* d_ovf,
               uint32_t* d_status, float* d_thr_next) {
@@ -637,32 +653,32 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
     const uint32_t capl = 256;
     const uint32_t n_wg = std::min<uint32_t>((uint32_t)ix->n_cu, (n + vdb::fused_bf16_tile_rows() - 1) / vdb::fused_bf16_tile_rows());
     const uint32_t n_sub = vdb::fused_bf16_subpools_per_query(n_wg);
-    if ((rc = ix->w_dense.ensure((size_t)SUPER * M))) return rc;
-    if ((rc = ix->w_cand.ensure((size_t)SUPER * kp))) return rc;
-    if ((rc = ix->w_samp.ensure((size_t)SUPER * std::max(kp, KT)))) return rc;
-    if ((rc = ix->w_pool.ensure((size_t)SUPER * n_sub * capl))) return rc;
-    if ((rc = ix->w_subcnt.ensure((size_t)SUPER * n_sub))) return rc;
-    uint32_t* d_cnt_a = ix->w_cnt.p;
-    uint32_t* d_cand_cnt = ix->w_cnt.p + 2 * SUPER;
-    ix->stats[4] = S;
+    if ((rc = ix->cur->w_dense.ensure((size_t)SUPER * M))) return rc;
+    if ((rc = ix->cur->w_cand.ensure((size_t)SUPER * kp))) return rc;
+    if ((rc = ix->cur->w_samp.ensure((size_t)SUPER * std::max(kp, KT)))) return rc;
+    if ((rc = ix->cur->w_pool.ensure((size_t)SUPER * n_sub * capl))) return rc;
+    if ((rc = ix->cur->w_subcnt.ensure((size_t)SUPER * n_sub))) return rc;
+    uint32_t* d_cnt_a = ix->cur->w_cnt.p;
+    uint32_t* d_cand_cnt = ix->cur->w_cnt.p + 2 * SUPER;
+    ix->cur->stats[4] = S;
     const float eps = eps_coef(ix);
     for (uint32_t q0 = 0; q0 < nq; q0 += SUPER) {
         const uint32_t nb = std::min(SUPER, nq - q0);
         vdb::FusedBf16Params fp{};
-        fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w_qb.p + (size_t)q0 * ld;
+        fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->cur->w_qb.p + (size_t)q0 * ld;
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
-        fp.margin = ix->d_margin; fp.qg = ix->d_margin ? ix->w_qg.p + q0 : nullptr;
-        fp.thr = ix->w_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
+        fp.margin = ix->d_margin; fp.qg = ix->d_margin ? ix->cur->w_qg.p + q0 : nullptr;
+        fp.thr = ix->cur->w_thr.p + q0; fp.pool = ix->cur->w_pool.p; fp.pool_cnt = ix->cur->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
         fp.ablate = ix->kn.bf16_ablate;
         fp.n_sample = S; fp.sample_shift = pl.shift;
-        fp.sample_block = ix->kn.sample_block ? (n / (S / 256u)) : 0u; fp.minkeys = ix->w_dense.p; fp.minkey_stride = M;
+        fp.sample_block = ix->kn.sample_block ? (n / (S / 256u)) : 0u; fp.minkeys = ix->cur->w_dense.p; fp.minkey_stride = M;
         vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);    // (the sample always reads the f32 rows)
 
         vdb::SelectParams sp{};
-        sp.keys = ix->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = KT;
-        sp.out_stride = KT; sp.out_keys = ix->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->w_thr.p + q0; sp.ovf = nullptr;
-        if (ix->d_margin) { sp.shift_g = ix->w_qg.p + q0; sp.shift_m_bits = ix->d_scalars + 4; }   // plain-score sample -> lower-bound units
-        vdb::launch_select(sp, nb, s);
+        sp.keys = ix->cur->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = KT;
+        sp.out_stride = KT; sp.out_keys = ix->cur->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->cur->w_thr.p + q0; sp.ovf = nullptr;
+        if (ix->d_margin) { sp.shift_g = ix->cur->w_qg.p + q0; sp.shift_m_bits = ix->d_scalars + 4; }   // plain-score sample -> lower-bound units
+        vdb::launch_thr_select(sp, nb, s);
 
         if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
 #ifdef VDB_DIAG
@@ -675,39 +691,39 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
             HIP_TRY(hipEventSynchronize(ix->ev1));
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
-            ix->stats[7] += (uint64_t)((double)ms * 1e6);
+            ix->cur->stats[7] += (uint64_t)((double)ms * 1e6);
         }
-        ix->stats[3] += n;
+        ix->cur->stats[3] += n;
 
         vdb::SelectParams mp{};
-        mp.keys = ix->w_pool.p; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
-        mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl; mp.wg_major = 1;
-        mp.kk = kp; mp.out_keys = ix->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
+        mp.keys = ix->cur->w_pool.p; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
+        mp.sub_counts = ix->cur->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl; mp.wg_major = 1;
+        mp.kk = kp; mp.out_keys = ix->cur->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
         mp.out_thr = nullptr; mp.ovf = d_ovf + q0; mp.summary = d_status + 1;
         vdb::launch_select(mp, nb, s);
 
         vdb::RerankParams rp{};
         rp.rows = ix->d_rows; rp.ld = ld; rp.dim = ix->dim; rp.n_rows = n;
-        rp.qp = ix->w_qp.p + (size_t)q0 * ld; rp.qnorm = ix->w_qnorm.p + q0; rp.nd = ix->d_nd; rp.row_ids = ix->d_row_ids;
-        rp.rowmask = d_rowmask; rp.cand = ix->w_cand.p; rp.cand_stride = kp; rp.cand_cnt = d_cand_cnt; rp.kp = kp;
+        rp.qp = ix->cur->w_qp.p + (size_t)q0 * ld; rp.qnorm = ix->cur->w_qnorm.p + q0; rp.nd = ix->d_nd; rp.row_ids = ix->d_row_ids;
+        rp.rowmask = d_rowmask; rp.cand = ix->cur->w_cand.p; rp.cand_stride = kp; rp.cand_cnt = d_cand_cnt; rp.kp = kp;
         rp.metric = ix->metric; rp.k = (uint32_t)k; rp.eps_coef = eps; rp.nd2max_bits = ix->d_scalars;
         rp.out_ids = d_out_ids + (size_t)q0 * k; rp.out_dists = d_out_dists + (size_t)q0 * k;
         rp.out_counts = d_out_counts + q0; rp.out_stride = (uint32_t)k; rp.cert = d_cert + q0; rp.status = d_status;
-        rp.thr = ix->w_thr.p + q0;
-        rp.qerr = ix->w_qerr.p + q0; rp.c_acc = c_acc_bf16(ix); rp.lb_scores = ix->d_margin ? 1u : 0u;
+        rp.thr = ix->cur->w_thr.p + q0;
+        rp.qerr = ix->cur->w_qerr.p + q0; rp.c_acc = c_acc_bf16(ix); rp.lb_scores = ix->d_margin ? 1u : 0u;
         rp.kp_first = round_up((uint32_t)k + 38u, 16u); rp.kp_step = 32;
         rp.thr_next = d_thr_next ? d_thr_next + q0 : nullptr;
         // diagnostics build: the first re-rank round overridden, the depth each query ended at printed
         if (ix->kn.kp_first) rp.kp_first = ix->kn.kp_first;
         const bool dump_depth = ix->kn.rr_depth;
         if (dump_depth) {
-            if ((rc = ix->w_depth.ensure(SUPER))) return rc;
-            rp.depth = ix->w_depth.p;
+            if ((rc = ix->cur->w_depth.ensure(SUPER))) return rc;
+            rp.depth = ix->cur->w_depth.p;
         }
         vdb::launch_rerank(rp, nb, s);
         if (dump_depth) {
             std::vector<uint32_t> dep(nb);
-            HIP_TRY(hipMemcpyAsync(dep.data(), ix->w_depth.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(dep.data(), ix->cur->w_depth.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             std::sort(dep.begin(), dep.end());
             fprintf(stderr, "[vdb] re-rank depth of %u queries: min %u  p25 %u  median %u  p75 %u  p95 %u  max %u  (first round %u)\n", nb,
@@ -735,60 +751,60 @@ int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo
     const uint32_t capl = 256;
     const uint32_t n_wg = std::min<uint32_t>((uint32_t)ix->n_cu, (n + vdb::fused_bf16_tile_rows() - 1) / vdb::fused_bf16_tile_rows());
     const uint32_t n_sub = vdb::fused_bf16_subpools_per_query(n_wg);
-    if ((rc = ix->w2_qp.ensure((size_t)nfp * ld))) return rc;
-    if ((rc = ix->w2_qnorm.ensure(nfp))) return rc;
-    if ((rc = ix->w2_thr.ensure(nfp))) return rc;
-    if ((rc = ix->w2_qerr.ensure(nfp))) return rc;
-    if ((rc = ix->w2_qg.ensure(nfp))) return rc;
-    if ((rc = ix->w2_qb.ensure((size_t)nfp * ld))) return rc;
-    if ((rc = ix->w2_outi.ensure((size_t)nf * k))) return rc;
-    if ((rc = ix->w2_outd.ensure((size_t)nf * k))) return rc;
-    if ((rc = ix->w2_outc.ensure(nf))) return rc;
-    if ((rc = ix->w2_flags.ensure(2 * (size_t)nf))) return rc;
-    if ((rc = ix->w2_qidx.ensure(nf))) return rc;
-    if ((rc = ix->w2_cand.ensure((size_t)SUPER * KMAX))) return rc;
-    if ((rc = ix->w_pool.ensure((size_t)SUPER * n_sub * capl))) return rc;
-    if ((rc = ix->w_subcnt.ensure((size_t)SUPER * n_sub))) return rc;
-    uint32_t* d_cert2 = ix->w2_flags.p;
-    uint32_t* d_ovf2 = ix->w2_flags.p + nf;
-    HIP_TRY(hipMemcpyAsync(ix->w2_qidx.p, todo.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
-    vdb::launch_gather_queries(ix->w_qp.p, ix->w_qnorm.p, ld, ix->w2_qidx.p, nf, nfp, ix->w2_qp.p, ix->w2_qnorm.p, ix->w2_thr.p, s);
+    if ((rc = ix->cur->w2_qp.ensure((size_t)nfp * ld))) return rc;
+    if ((rc = ix->cur->w2_qnorm.ensure(nfp))) return rc;
+    if ((rc = ix->cur->w2_thr.ensure(nfp))) return rc;
+    if ((rc = ix->cur->w2_qerr.ensure(nfp))) return rc;
+    if ((rc = ix->cur->w2_qg.ensure(nfp))) return rc;
+    if ((rc = ix->cur->w2_qb.ensure((size_t)nfp * ld))) return rc;
+    if ((rc = ix->cur->w2_outi.ensure((size_t)nf * k))) return rc;
+    if ((rc = ix->cur->w2_outd.ensure((size_t)nf * k))) return rc;
+    if ((rc = ix->cur->w2_outc.ensure(nf))) return rc;
+    if ((rc = ix->cur->w2_flags.ensure(2 * (size_t)nf))) return rc;
+    if ((rc = ix->cur->w2_qidx.ensure(nf))) return rc;
+    if ((rc = ix->cur->w2_cand.ensure((size_t)SUPER * KMAX))) return rc;
+    if ((rc = ix->cur->w_pool.ensure((size_t)SUPER * n_sub * capl))) return rc;
+    if ((rc = ix->cur->w_subcnt.ensure((size_t)SUPER * n_sub))) return rc;
+    uint32_t* d_cert2 = ix->cur->w2_flags.p;
+    uint32_t* d_ovf2 = ix->cur->w2_flags.p + nf;
+    HIP_TRY(hipMemcpyAsync(ix->cur->w2_qidx.p, todo.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
+    vdb::launch_gather_queries(ix->cur->w_qp.p, ix->cur->w_qnorm.p, ld, ix->cur->w2_qidx.p, nf, nfp, ix->cur->w2_qp.p, ix->cur->w2_qnorm.p, ix->cur->w2_thr.p, s);
     // bf16 image, |q - bf16(q)| and zeroed flags of the compact block (the rows are already padded: dim = ld)
-    vdb::QueryPrepParams qp{ix->w2_qp.p, ld, nf, ix->w2_qp.p, ld, nfp, ix->w2_qnorm.p, ix->w2_thr.p, vdb::EUCLID, d_status,
-                            ix->w2_qb.p, ix->w2_qerr.p, ix->d_margin ? ix->w2_qg.p : nullptr, margin_plan(ix).kappa, d_cert2, d_ovf2};
+    vdb::QueryPrepParams qp{ix->cur->w2_qp.p, ld, nf, ix->cur->w2_qp.p, ld, nfp, ix->cur->w2_qnorm.p, ix->cur->w2_thr.p, vdb::EUCLID, d_status,
+                            ix->cur->w2_qb.p, ix->cur->w2_qerr.p, ix->d_margin ? ix->cur->w2_qg.p : nullptr, margin_plan(ix).kappa, d_cert2, d_ovf2};
     vdb::launch_query_prep(qp, s);
-    HIP_TRY(hipMemcpyAsync(ix->w2_thr.p, cuts.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));   // padding queries keep -inf
-    uint32_t* d_cand_cnt = ix->w_cnt.p + 2 * SUPER;
+    HIP_TRY(hipMemcpyAsync(ix->cur->w2_thr.p, cuts.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));   // padding queries keep -inf
+    uint32_t* d_cand_cnt = ix->cur->w_cnt.p + 2 * SUPER;
     for (uint32_t q0 = 0; q0 < nf; q0 += SUPER) {
         const uint32_t nb = std::min(SUPER, nf - q0);
         vdb::FusedBf16Params fp{};
-        fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w2_qb.p + (size_t)q0 * ld;
+        fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->cur->w2_qb.p + (size_t)q0 * ld;
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
-        fp.margin = ix->d_margin; fp.qg = ix->d_margin ? ix->w2_qg.p + q0 : nullptr;
-        fp.thr = ix->w2_thr.p + q0; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
+        fp.margin = ix->d_margin; fp.qg = ix->d_margin ? ix->cur->w2_qg.p + q0 : nullptr;
+        fp.thr = ix->cur->w2_thr.p + q0; fp.pool = ix->cur->w_pool.p; fp.pool_cnt = ix->cur->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
 #ifdef VDB_DIAG
         if (!ix->kn.fused_pipe) vdb::launch_fused_bf16(fp, s);
         else
 #endif
         vdb::launch_fused_bf16p(fp, s);
-        ix->stats[3] += n;
+        ix->cur->stats[3] += n;
         vdb::SelectParams mp{};
-        mp.keys = ix->w_pool.p; mp.sub_counts = ix->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl; mp.wg_major = 1;
-        mp.kk = KMAX; mp.out_keys = ix->w2_cand.p; mp.out_stride = KMAX; mp.out_cnt = d_cand_cnt;
+        mp.keys = ix->cur->w_pool.p; mp.sub_counts = ix->cur->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl; mp.wg_major = 1;
+        mp.kk = KMAX; mp.out_keys = ix->cur->w2_cand.p; mp.out_stride = KMAX; mp.out_cnt = d_cand_cnt;
         mp.ovf = d_ovf2 + q0; mp.summary = nullptr; mp.flag_truncation = 1;
         vdb::launch_select(mp, nb, s);
         vdb::RerankParams rp{};
         rp.rows = ix->d_rows; rp.ld = ld; rp.dim = ix->dim; rp.n_rows = n;
-        rp.qp = ix->w2_qp.p + (size_t)q0 * ld; rp.qnorm = ix->w2_qnorm.p + q0; rp.nd = ix->d_nd; rp.row_ids = ix->d_row_ids;
-        rp.rowmask = d_rowmask; rp.cand = ix->w2_cand.p; rp.cand_stride = KMAX; rp.cand_cnt = d_cand_cnt; rp.kp = KMAX;
+        rp.qp = ix->cur->w2_qp.p + (size_t)q0 * ld; rp.qnorm = ix->cur->w2_qnorm.p + q0; rp.nd = ix->d_nd; rp.row_ids = ix->d_row_ids;
+        rp.rowmask = d_rowmask; rp.cand = ix->cur->w2_cand.p; rp.cand_stride = KMAX; rp.cand_cnt = d_cand_cnt; rp.kp = KMAX;
         rp.metric = ix->metric; rp.k = (uint32_t)k; rp.nd2max_bits = ix->d_scalars;
-        rp.out_ids = ix->w2_outi.p + (size_t)q0 * k; rp.out_dists = ix->w2_outd.p + (size_t)q0 * k;
-        rp.out_counts = ix->w2_outc.p + q0; rp.out_stride = (uint32_t)k; rp.cert = d_cert2 + q0; rp.status = d_status;
+        rp.out_ids = ix->cur->w2_outi.p + (size_t)q0 * k; rp.out_dists = ix->cur->w2_outd.p + (size_t)q0 * k;
+        rp.out_counts = ix->cur->w2_outc.p + q0; rp.out_stride = (uint32_t)k; rp.cert = d_cert2 + q0; rp.status = d_status;
         vdb::launch_rerank_all(rp, nb, s);
     }
     HIP_TRY(hipGetLastError());
     flags2.assign(2 * (size_t)nf, 0u);
-    HIP_TRY(hipMemcpyAsync(flags2.data(), ix->w2_flags.p, 2 * (size_t)nf * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(flags2.data(), ix->cur->w2_flags.p, 2 * (size_t)nf * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     // only the queries this pass answered completely are written back
     std::vector<uint32_t> good;
@@ -797,9 +813,9 @@ int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo
         // scatter compact results j -> batch position todo[j] (the scatter kernel walks a (source, destination) list)
         std::vector<uint32_t> src_dst(2 * good.size());
         for (size_t i = 0; i < good.size(); ++i) { src_dst[i] = good[i]; src_dst[good.size() + i] = todo[good[i]]; }
-        if ((rc = ix->w2_qidx.ensure(2 * good.size()))) return rc;
-        HIP_TRY(hipMemcpyAsync(ix->w2_qidx.p, src_dst.data(), src_dst.size() * 4, hipMemcpyHostToDevice, s));
-        vdb::launch_scatter_results_list(ix->w2_outi.p, ix->w2_outd.p, ix->w2_outc.p, ix->w2_qidx.p, ix->w2_qidx.p + good.size(),
+        if ((rc = ix->cur->w2_qidx.ensure(2 * good.size()))) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->cur->w2_qidx.p, src_dst.data(), src_dst.size() * 4, hipMemcpyHostToDevice, s));
+        vdb::launch_scatter_results_list(ix->cur->w2_outi.p, ix->cur->w2_outd.p, ix->cur->w2_outc.p, ix->cur->w2_qidx.p, ix->cur->w2_qidx.p + good.size(),
                                          (uint32_t)good.size(), (uint32_t)k, d_out_ids, d_out_dists, d_out_counts, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(s));
@@ -813,15 +829,15 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
                  size_t mask_bits, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
                  hipStream_t user_stream) {
     int rc;
-    ix->ctx.pending = false;
+    ix->cur->ctx.pending = false;
     if ((rc = set_device(ix))) return rc;
     if ((rc = flush(ix))) return rc;
     if (nq == 0) return VDB_OK;
     // all launches of this search go to the caller's stream when one is given (so that the caller's
     // events bracket them); the workspace is protected by the handle mutex and the final sync
-    hipStream_t s = user_stream ? user_stream : ix->stream;
-    memset(ix->stats, 0, sizeof(ix->stats));
-    ix->stats[15] = ix->kn.any ? 1u : 0u;          // diagnostics build with a knob set: the run is NOT covered by the exactness guarantee
+    hipStream_t s = user_stream ? user_stream : ix->cur->stream;
+    memset(ix->cur->stats, 0, sizeof(ix->cur->stats));
+    ix->cur->stats[15] = ix->kn.any ? 1u : 0u;          // diagnostics build with a knob set: the run is NOT covered by the exactness guarantee
     const auto t_entry = std::chrono::steady_clock::now();
     auto since = [&]() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_entry).count(); };
     size_t total_rows = ix->n_live + ix->misfits.size();
@@ -853,69 +869,69 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
     const uint32_t kp = pick_kp(k);
 
     // ---- workspace
-    if ((rc = ix->w_qp.ensure((size_t)bp_all * ld))) return rc;
-    if ((rc = ix->w_qnorm.ensure(bp_all))) return rc;
-    if ((rc = ix->w_thr.ensure(bp_all))) return rc;
-    if ((rc = ix->w_flags.ensure(4 + 3 * (size_t)nq32))) return rc;      // status block | cert | overflow | score cut per query
-    if (ix->h_flags_n < 4 + 3 * (size_t)nq32) {
-        if (ix->h_flags) (void)hipHostFree(ix->h_flags);
-        ix->h_flags = nullptr;
-        ix->h_flags_n = 0;
+    if ((rc = ix->cur->w_qp.ensure((size_t)bp_all * ld))) return rc;
+    if ((rc = ix->cur->w_qnorm.ensure(bp_all))) return rc;
+    if ((rc = ix->cur->w_thr.ensure(bp_all))) return rc;
+    if ((rc = ix->cur->w_flags.ensure(4 + 3 * (size_t)nq32))) return rc;      // status block | cert | overflow | score cut per query
+    if (ix->cur->h_flags_n < 4 + 3 * (size_t)nq32) {
+        if (ix->cur->h_flags) (void)hipHostFree(ix->cur->h_flags);
+        ix->cur->h_flags = nullptr;
+        ix->cur->h_flags_n = 0;
         size_t want = 4 + 3 * (size_t)nq32 + 1024;
-        HIP_TRY(hipHostMalloc((void**)&ix->h_flags, want * 4, hipHostMallocDefault));
-        ix->h_flags_n = want;
+        HIP_TRY(hipHostMalloc((void**)&ix->cur->h_flags, want * 4, hipHostMallocDefault));
+        ix->cur->h_flags_n = want;
     }
-    uint32_t* d_status = ix->w_flags.p;        // [0] status bits
-    uint32_t* d_cert = ix->w_flags.p + 4;      // [nq]
+    uint32_t* d_status = ix->cur->w_flags.p;        // [0] status bits
+    uint32_t* d_cert = ix->cur->w_flags.p + 4;      // [nq]
     uint32_t* d_ovf = d_cert + nq32;           // [nq]
     // the per-query flags are zeroed by query_prep; the 16-byte status block only needs a memset when the last
     // search left it set (or the buffer is new) -- one launch less at the head of every search
     const bool flags_by_prep = kp != 0 || (ix->screen && plan_bf16(ix, n, k).kp);
-    if (!flags_by_prep) HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, (4 + 3 * (size_t)nq32) * 4, s));
-    else if (ix->status_dirty || ix->w_flags.p != ix->status_buf) {
-        HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, 16, s));
-        ix->status_buf = ix->w_flags.p;
+    if (!flags_by_prep) HIP_TRY(hipMemsetAsync(ix->cur->w_flags.p, 0, (4 + 3 * (size_t)nq32) * 4, s));
+    else if (ix->cur->status_dirty || ix->cur->w_flags.p != ix->cur->status_buf) {
+        HIP_TRY(hipMemsetAsync(ix->cur->w_flags.p, 0, 16, s));
+        ix->cur->status_buf = ix->cur->w_flags.p;
     }
-    ix->status_dirty = true;                               // until a clean status word has been read back
+    ix->cur->status_dirty = true;                               // until a clean status word has been read back
 
     // ---- eligibility mask: tombstones, optionally AND the caller's id filter
     const uint32_t* d_rowmask = (ix->n_live == n) ? nullptr : ix->d_live;
     if (d_idmask) {
-        if ((rc = ix->w_rowmask.ensure((n + 31) / 32))) return rc;
-        vdb::launch_build_rowmask(ix->d_row_ids, d_rowmask, d_idmask, mask_bits, n, ix->w_rowmask.p, s);
-        d_rowmask = ix->w_rowmask.p;
+        if ((rc = ix->cur->w_rowmask.ensure((n + 31) / 32))) return rc;
+        vdb::launch_build_rowmask(ix->d_row_ids, d_rowmask, d_idmask, mask_bits, n, ix->cur->w_rowmask.p, s);
+        d_rowmask = ix->cur->w_rowmask.p;
     }
 
     // ---- queries: zero-padded copy + exact-order norms
     {
         uint16_t* qb = nullptr;
         if (ix->screen && plan_bf16(ix, n, k).kp) {
-            if ((rc = ix->w_qb.ensure((size_t)bp_all * ld))) return rc;
-            if ((rc = ix->w_qerr.ensure(bp_all))) return rc;
-            if ((rc = ix->w_qg.ensure(bp_all))) return rc;
-            qb = ix->w_qb.p;
+            if ((rc = ix->cur->w_qb.ensure((size_t)bp_all * ld))) return rc;
+            if ((rc = ix->cur->w_qerr.ensure(bp_all))) return rc;
+            if ((rc = ix->cur->w_qg.ensure(bp_all))) return rc;
+            qb = ix->cur->w_qb.p;
         }
-        vdb::QueryPrepParams qp{d_q, (uint32_t)dim, nq32, ix->w_qp.p, ld, bp_all, ix->w_qnorm.p, ix->w_thr.p, ix->metric, d_status, qb,
-                                ix->w_qerr.p, (qb && ix->d_margin) ? ix->w_qg.p : nullptr, margin_plan(ix).kappa,
+        vdb::QueryPrepParams qp{d_q, (uint32_t)dim, nq32, ix->cur->w_qp.p, ld, bp_all, ix->cur->w_qnorm.p, ix->cur->w_thr.p, ix->metric, d_status, qb,
+                                ix->cur->w_qerr.p, (qb && ix->d_margin) ? ix->cur->w_qg.p : nullptr, margin_plan(ix).kappa,
                                 flags_by_prep ? d_cert : nullptr, flags_by_prep ? d_ovf : nullptr};
         vdb::launch_query_prep(qp, s);
     }
 
     if (kp == 0 && !(ix->screen && plan_bf16(ix, n, k).kp)) {
         // large k: exact scan for every query
-        HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ix->cur->h_flags, ix->cur->w_flags.p, 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (ix->h_flags[0] & vdb::ST_ZERO_QUERY)
+        if (ix->cur->h_flags[0] & vdb::ST_ZERO_QUERY)
             return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
         for (uint32_t q = 0; q < nq32; ++q) {
             if ((rc = exact_one(ix, s, q, k, d_rowmask, d_out_ids + (size_t)q * k, d_out_dists + (size_t)q * k,
                                 d_out_counts + q)))
                 return rc;
         }
-        ix->stats[1] = nq32;
-        HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, 16, hipMemcpyDeviceToHost, s));
+        ix->cur->stats[1] = nq32;
+        HIP_TRY(hipMemcpyAsync(ix->cur->h_flags, ix->cur->w_flags.p, 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (ix->h_flags[0] & vdb::ST_NAN) return fail(VDB_ERR_NAN, "NaN distance (the reference panics here, flat_index.rs:62)");
+        if (ix->cur->h_flags[0] & vdb::ST_NAN) return fail(VDB_ERR_NAN, "NaN distance (the reference panics here, flat_index.rs:62)");
         return VDB_OK;
     }
 
@@ -923,22 +939,22 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
     // are re-run as a compact block by the f32 MFMA tier; whatever that cannot certify goes to the exact scan.
     const Bf16Plan pl16 = ix->screen ? plan_bf16(ix, n, k) : Bf16Plan{};
     const uint32_t kp16 = pl16.kp;
-    if ((rc = ix->w_cnt.ensure(4 * SUPER + 16))) return rc;
+    if ((rc = ix->cur->w_cnt.ensure(4 * SUPER + 16))) return rc;
     if (kp16) {
-        ix->stats[8] = 1;
-        ix->stats[5] = kp16;
+        ix->cur->stats[8] = 1;
+        ix->cur->stats[5] = kp16;
         if ((rc = pass_bf16(ix, s, nq32, k, pl16, d_rowmask, d_out_ids, d_out_dists, d_out_counts, d_cert, d_ovf, d_status,
                             reinterpret_cast<float*>(d_ovf + nq32))))
             return rc;
     } else {
-        if ((rc = pass_f32(ix, s, ix->w_qp.p, ix->w_qnorm.p, ix->w_thr.p, nq32, k, kp, d_rowmask, d_out_ids, d_out_dists,
+        if ((rc = pass_f32(ix, s, ix->cur->w_qp.p, ix->cur->w_qnorm.p, ix->cur->w_thr.p, nq32, k, kp, d_rowmask, d_out_ids, d_out_dists,
                            d_out_counts, d_cert, d_ovf, d_status)))
             return rc;
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, (4 + 3 * (size_t)nq32) * 4, hipMemcpyDeviceToHost, s));
-    ix->stats[10] = since();                       // host time until everything of the first tier is enqueued, ns
-    Index::SearchCtx& c = ix->ctx;
+    HIP_TRY(hipMemcpyAsync(ix->cur->h_flags, ix->cur->w_flags.p, (4 + 3 * (size_t)nq32) * 4, hipMemcpyDeviceToHost, s));
+    ix->cur->stats[10] = since();                       // host time until everything of the first tier is enqueued, ns
+    Workspace::SearchCtx& c = ix->cur->ctx;
     c.pending = true; c.nq32 = nq32; c.kp = kp; c.kp16 = kp16; c.k = k; c.s = s; c.d_rowmask = d_rowmask;
     c.d_out_ids = d_out_ids; c.d_out_dists = d_out_dists; c.d_out_counts = d_out_counts; c.t_entry = t_entry;
     return VDB_OK;
@@ -948,7 +964,7 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
 // *changed (may be null) tells whether outputs were rewritten after part 1's pass.
 int search_part2(Index* ix, int* changed) {
     if (changed) *changed = 0;
-    Index::SearchCtx& c = ix->ctx;
+    Workspace::SearchCtx& c = ix->cur->ctx;
     if (!c.pending) return VDB_OK;
     c.pending = false;
     int rc;
@@ -958,12 +974,12 @@ int search_part2(Index* ix, int* changed) {
     const uint32_t* d_rowmask = c.d_rowmask;
     uint64_t* d_out_ids = c.d_out_ids; float* d_out_dists = c.d_out_dists; uint32_t* d_out_counts = c.d_out_counts;
     const uint32_t n = ix->n_uploaded, ld = ix->ld;
-    uint32_t* d_status = ix->w_flags.p;
+    uint32_t* d_status = ix->cur->w_flags.p;
     const auto t_entry = c.t_entry;
     auto since = [&]() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_entry).count(); };
     HIP_TRY(hipStreamSynchronize(s));
-    ix->stats[11] = since();                       // ... until the first tier's flags are on the host, ns
-    uint32_t status = ix->h_flags[0];
+    ix->cur->stats[11] = since();                       // ... until the first tier's flags are on the host, ns
+    uint32_t status = ix->cur->h_flags[0];
     if (status & vdb::ST_ZERO_QUERY)
         return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
     // vdb_flat_set_tiers: forced hand-over to the slower tiers (tests); every tier returns the same results
@@ -972,17 +988,17 @@ int search_part2(Index* ix, int* changed) {
     const bool no_rethr = (ix->tiers & VDB_TIERS_NO_RETHRESHOLD) != 0;
     std::vector<uint32_t> todo;
     for (uint32_t q = 0; q < nq32; ++q) {
-        bool cert = ix->h_flags[4 + q] != 0, ovf = ix->h_flags[4 + nq32 + q] != 0;
-        if (ovf) ++ix->stats[2];
-        if (!cert) ++ix->stats[6];
+        bool cert = ix->cur->h_flags[4 + q] != 0, ovf = ix->cur->h_flags[4 + nq32 + q] != 0;
+        if (ovf) ++ix->cur->stats[2];
+        if (!cert) ++ix->cur->stats[6];
         if (cert && !ovf && !force_exact && !(kp16 && force_f32)) continue;
         todo.push_back(q);
     }
     if (changed && !todo.empty()) *changed = 1;
     if (kp16 && !todo.empty() && !no_rethr && !force_exact && !force_f32) {
         // ---- tier 0b: queries with a known score cut get one more HBM-bound pass with that cut as the threshold
-        const uint32_t* h_ovf = ix->h_flags + 4 + nq32;
-        const float* h_cut = reinterpret_cast<const float*>(ix->h_flags + 4 + 2 * (size_t)nq32);
+        const uint32_t* h_ovf = ix->cur->h_flags + 4 + nq32;
+        const float* h_cut = reinterpret_cast<const float*>(ix->cur->h_flags + 4 + 2 * (size_t)nq32);
         std::vector<uint32_t> sel, rest;
         std::vector<float> cuts;
         for (uint32_t q : todo) {
@@ -995,8 +1011,8 @@ int search_part2(Index* ix, int* changed) {
             if ((rc = pass_rethreshold(ix, s, sel, cuts, k, d_rowmask, d_out_ids, d_out_dists, d_out_counts, d_status, fl))) return rc;
             const uint32_t nf = (uint32_t)sel.size();
             for (uint32_t j = 0; j < nf; ++j) {
-                if (fl[j] && !fl[nf + j]) ++ix->stats[13];
-                else { rest.push_back(sel[j]); if (fl[nf + j]) ++ix->stats[2]; }
+                if (fl[j] && !fl[nf + j]) ++ix->cur->stats[13];
+                else { rest.push_back(sel[j]); if (fl[nf + j]) ++ix->cur->stats[2]; }
             }
             std::sort(rest.begin(), rest.end());
         }
@@ -1005,32 +1021,32 @@ int search_part2(Index* ix, int* changed) {
     if (kp16 && !todo.empty()) {
         // ---- second tier: the uncertified queries as one compact block through the f32 MFMA pipeline
         const uint32_t nf = (uint32_t)todo.size(), nfp = round_up(nf, SUPER);
-        ix->stats[9] = nf;
-        if ((rc = ix->w2_qp.ensure((size_t)nfp * ld))) return rc;
-        if ((rc = ix->w2_qnorm.ensure(nfp))) return rc;
-        if ((rc = ix->w2_thr.ensure(nfp))) return rc;
-        if ((rc = ix->w2_outi.ensure((size_t)nf * k))) return rc;
-        if ((rc = ix->w2_outd.ensure((size_t)nf * k))) return rc;
-        if ((rc = ix->w2_outc.ensure(nf))) return rc;
-        if ((rc = ix->w2_flags.ensure(2 * (size_t)nf))) return rc;
-        if ((rc = ix->w2_qidx.ensure(nf))) return rc;
-        HIP_TRY(hipMemcpyAsync(ix->w2_qidx.p, todo.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemsetAsync(ix->w2_flags.p, 0, 2 * (size_t)nf * 4, s));
-        vdb::launch_gather_queries(ix->w_qp.p, ix->w_qnorm.p, ld, ix->w2_qidx.p, nf, nfp, ix->w2_qp.p, ix->w2_qnorm.p,
-                                   ix->w2_thr.p, s);
+        ix->cur->stats[9] = nf;
+        if ((rc = ix->cur->w2_qp.ensure((size_t)nfp * ld))) return rc;
+        if ((rc = ix->cur->w2_qnorm.ensure(nfp))) return rc;
+        if ((rc = ix->cur->w2_thr.ensure(nfp))) return rc;
+        if ((rc = ix->cur->w2_outi.ensure((size_t)nf * k))) return rc;
+        if ((rc = ix->cur->w2_outd.ensure((size_t)nf * k))) return rc;
+        if ((rc = ix->cur->w2_outc.ensure(nf))) return rc;
+        if ((rc = ix->cur->w2_flags.ensure(2 * (size_t)nf))) return rc;
+        if ((rc = ix->cur->w2_qidx.ensure(nf))) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->cur->w2_qidx.p, todo.data(), (size_t)nf * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(ix->cur->w2_flags.p, 0, 2 * (size_t)nf * 4, s));
+        vdb::launch_gather_queries(ix->cur->w_qp.p, ix->cur->w_qnorm.p, ld, ix->cur->w2_qidx.p, nf, nfp, ix->cur->w2_qp.p, ix->cur->w2_qnorm.p,
+                                   ix->cur->w2_thr.p, s);
         if (kp == 0) {
             // k too large for the f32 tier as well: straight to the exact scan (flags stay 0 = uncertified)
         } else {
-            if ((rc = pass_f32(ix, s, ix->w2_qp.p, ix->w2_qnorm.p, ix->w2_thr.p, nf, k, kp, d_rowmask, ix->w2_outi.p,
-                               ix->w2_outd.p, ix->w2_outc.p, ix->w2_flags.p, ix->w2_flags.p + nf, d_status)))
+            if ((rc = pass_f32(ix, s, ix->cur->w2_qp.p, ix->cur->w2_qnorm.p, ix->cur->w2_thr.p, nf, k, kp, d_rowmask, ix->cur->w2_outi.p,
+                               ix->cur->w2_outd.p, ix->cur->w2_outc.p, ix->cur->w2_flags.p, ix->cur->w2_flags.p + nf, d_status)))
                 return rc;
-            vdb::launch_scatter_results(ix->w2_outi.p, ix->w2_outd.p, ix->w2_outc.p, ix->w2_qidx.p, nf, (uint32_t)k,
+            vdb::launch_scatter_results(ix->cur->w2_outi.p, ix->cur->w2_outd.p, ix->cur->w2_outc.p, ix->cur->w2_qidx.p, nf, (uint32_t)k,
                                         d_out_ids, d_out_dists, d_out_counts, s);
         }
         HIP_TRY(hipGetLastError());
         std::vector<uint32_t> f2(2 * (size_t)nf + 4);
-        HIP_TRY(hipMemcpyAsync(f2.data(), ix->w2_flags.p, 2 * (size_t)nf * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(f2.data() + 2 * (size_t)nf, ix->w_flags.p, 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(f2.data(), ix->cur->w2_flags.p, 2 * (size_t)nf * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(f2.data() + 2 * (size_t)nf, ix->cur->w_flags.p, 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         status |= f2[2 * (size_t)nf];
         if (status & vdb::ST_ZERO_QUERY)
@@ -1038,7 +1054,7 @@ int search_part2(Index* ix, int* changed) {
         std::vector<uint32_t> todo2;
         for (uint32_t j = 0; j < nf; ++j) {
             bool cert = f2[j] != 0, ovf = f2[nf + j] != 0;
-            if (ovf) ++ix->stats[2];
+            if (ovf) ++ix->cur->stats[2];
             if (cert && !ovf && !force_exact) continue;
             todo2.push_back(todo[j]);
         }
@@ -1052,29 +1068,29 @@ int search_part2(Index* ix, int* changed) {
     if (!todo.empty()) {
         const uint32_t cap = 32768;
         if ((rc = ensure_ranks(ix))) return rc;
-        if ((rc = ix->w_exact.ensure(std::max<size_t>((size_t)8 * cap, n)))) return rc;
-        if ((rc = ix->w_exsel.ensure((size_t)8 * MAX_SELECT + 8))) return rc;
-        uint32_t* d_cnt8 = ix->w_cnt.p + 3 * SUPER;            // [8] survivors per query, [8..16) select counts
+        if ((rc = ix->cur->w_exact.ensure(std::max<size_t>((size_t)8 * cap, n)))) return rc;
+        if ((rc = ix->cur->w_exsel.ensure((size_t)8 * MAX_SELECT + 8))) return rc;
+        uint32_t* d_cnt8 = ix->cur->w_cnt.p + 3 * SUPER;            // [8] survivors per query, [8..16) select counts
         std::vector<uint32_t> dense;                             // queries whose bounded pass overflowed
         for (size_t g0 = 0; g0 < todo.size(); g0 += 8) {
             const uint32_t nqf = (uint32_t)std::min<size_t>(8, todo.size() - g0);
             HIP_TRY(hipMemsetAsync(d_cnt8, 0, 16 * 4, s));
             vdb::ExactMultiParams ep{};
-            ep.rows = ix->d_rows; ep.ld = ld; ep.dim = ix->dim; ep.n_rows = n; ep.qp = ix->w_qp.p; ep.qnorm = ix->w_qnorm.p;
+            ep.rows = ix->d_rows; ep.ld = ld; ep.dim = ix->dim; ep.n_rows = n; ep.qp = ix->cur->w_qp.p; ep.qnorm = ix->cur->w_qnorm.p;
             ep.nd = ix->d_nd; ep.rowmask = d_rowmask; ep.idrank = ix->ids_monotone ? nullptr : ix->d_idrank.p;
             ep.metric = ix->metric; ep.nqf = nqf;
             for (uint32_t j = 0; j < nqf; ++j) ep.qidx[j] = todo[g0 + j];
             ep.prev_dists = d_out_dists; ep.prev_counts = d_out_counts; ep.k = (uint32_t)k;
-            ep.keys = ix->w_exact.p; ep.cap = cap; ep.cnt = d_cnt8; ep.status = d_status;
+            ep.keys = ix->cur->w_exact.p; ep.cap = cap; ep.cnt = d_cnt8; ep.status = d_status;
             vdb::launch_exact_multi(ep, s);
             uint32_t h_cnt[8];
             HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt8, nqf * 4, hipMemcpyDeviceToHost, s));
             vdb::SelectParams sp{};
-            sp.keys = ix->w_exact.p; sp.stride = cap; sp.counts = d_cnt8; sp.n_fixed = 0; sp.cap = cap; sp.kk = (uint32_t)k;
-            sp.out_keys = ix->w_exsel.p; sp.out_stride = MAX_SELECT; sp.out_cnt = d_cnt8 + 8;
+            sp.keys = ix->cur->w_exact.p; sp.stride = cap; sp.counts = d_cnt8; sp.n_fixed = 0; sp.cap = cap; sp.kk = (uint32_t)k;
+            sp.out_keys = ix->cur->w_exsel.p; sp.out_stride = MAX_SELECT; sp.out_cnt = d_cnt8 + 8;
             vdb::launch_select(sp, nqf, s);
             vdb::EmitMultiParams em{};
-            em.keys = ix->w_exsel.p; em.key_stride = MAX_SELECT; em.cnt = d_cnt8 + 8;
+            em.keys = ix->cur->w_exsel.p; em.key_stride = MAX_SELECT; em.cnt = d_cnt8 + 8;
             em.rank2row = ix->ids_monotone ? nullptr : ix->d_rank2row.p; em.row_ids = ix->d_row_ids;
             em.out_ids = d_out_ids; em.out_dists = d_out_dists; em.out_count = d_out_counts; em.k = (uint32_t)k; em.nqf = nqf;
             for (uint32_t j = 0; j < nqf; ++j) em.qidx[j] = todo[g0 + j];
@@ -1089,27 +1105,39 @@ int search_part2(Index* ix, int* changed) {
                                 d_out_counts + q)))
                 return rc;
     }
-    ix->stats[12] = since();                       // whole call, ns
-    ix->stats[0] = nq32 - n_fallback;
-    ix->stats[1] = n_fallback;
+    ix->cur->stats[12] = since();                       // whole call, ns
+    ix->cur->stats[0] = nq32 - n_fallback;
+    ix->cur->stats[1] = n_fallback;
     uint32_t st2 = status;
     if (n_fallback) {
-        HIP_TRY(hipMemcpyAsync(ix->h_flags, ix->w_flags.p, 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ix->cur->h_flags, ix->cur->w_flags.p, 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        st2 |= ix->h_flags[0];
+        st2 |= ix->cur->h_flags[0];
     }
-    ix->status_dirty = st2 != 0 || ix->stats[6] != 0 || ix->stats[2] != 0;      // status bits, or the summary word was set
+    ix->cur->status_dirty = st2 != 0 || ix->cur->stats[6] != 0 || ix->cur->stats[2] != 0;      // status bits, or the summary word was set
     if (st2 & vdb::ST_NAN)
         return fail(VDB_ERR_NAN, "NaN distance (the reference panics here, flat_index.rs:62)");
     return VDB_OK;
 }
 
+void publish_stats(Index* ix) { memcpy(ix->stats, ix->cur->stats, sizeof(ix->stats)); }
+
+// searches submitted and not yet waited for (vdb_flat_search_batch_device_submit): the row store must not change under them
+bool in_flight(const Index* ix) { return ix->wsv && (ix->wsv[0].busy || ix->wsv[1].busy); }
+int refuse_in_flight() { return fail(VDB_ERR_INVALID_ARGUMENT, "a submitted search is still in flight on this handle: wait for it first"); }
+
 int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, const uint64_t* d_idmask,
                   size_t mask_bits, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
                   hipStream_t user_stream) {
+    // a synchronous search takes a context no submitted search is using
+    ix->cur = ix->wsv[0].busy ? &ix->wsv[1] : &ix->wsv[0];
+    if (ix->cur->busy) return fail(VDB_ERR_INVALID_ARGUMENT, "two submitted searches are in flight on this handle: wait for one first");
     int rc = search_part1(ix, d_q, nq, dim, k, d_idmask, mask_bits, d_out_ids, d_out_dists, d_out_counts, user_stream);
-    if (rc) { ix->ctx.pending = false; return rc; }
-    return search_part2(ix, nullptr);
+    if (rc) { ix->cur->ctx.pending = false; publish_stats(ix); ix->cur = &ix->wsv[0]; return rc; }
+    rc = search_part2(ix, nullptr);
+    publish_stats(ix);
+    ix->cur = &ix->wsv[0];
+    return rc;
 }
 
 }  // namespace
@@ -1170,6 +1198,16 @@ int vdb_flat_create(int metric, int device, vdb_flat_index** out) {
         delete ix;
         return fail(VDB_ERR_DEVICE, "hipMalloc failed");
     }
+    ix->wsv = new Workspace[2];
+    ix->cur = &ix->wsv[0];
+    ix->wsv[0].stream = ix->stream;
+    if (hipStreamCreateWithFlags(&ix->wsv[1].stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipFree(ix->d_scalars);
+        (void)hipStreamDestroy(ix->stream);
+        delete[] ix->wsv;
+        delete ix;
+        return fail(VDB_ERR_DEVICE, "hipStreamCreate failed");
+    }
     *out = ix;
     return VDB_OK;
     });
@@ -1182,14 +1220,13 @@ void vdb_flat_destroy(vdb_flat_index* ix) {
     free_store(ix);
     if (ix->d_scalars) (void)hipFree(ix->d_scalars);
     ix->d_idrank.release(); ix->d_rank2row.release();
-    ix->w_qp.release(); ix->w_qnorm.release(); ix->w_thr.release(); ix->w_qin.release(); ix->w_outd.release();
-    ix->w_dense.release(); ix->w_samp.release(); ix->w_pool.release(); ix->w_cand.release(); ix->w_exact.release();
-    ix->w_exsel.release(); ix->w_mask_ids.release(); ix->w_outi.release();
-    ix->w_qb.release(); ix->w_qerr.release(); ix->w2_qp.release(); ix->w2_qnorm.release(); ix->w2_thr.release(); ix->w2_outd.release();
-    ix->w2_qerr.release(); ix->w2_cand.release(); ix->w2_qb.release(); ix->w_qg.release(); ix->w2_qg.release(); ix->w_dbg.release();
-    ix->w2_outi.release(); ix->w2_outc.release(); ix->w2_flags.release(); ix->w2_qidx.release();
-    ix->w_cnt.release(); ix->w_subcnt.release(); ix->w_rowmask.release(); ix->w_flags.release(); ix->w_outc.release(); ix->w_depth.release();
-    if (ix->h_flags) (void)hipHostFree(ix->h_flags);
+    for (int w = 0; ix->wsv && w < 2; ++w) {
+        Workspace& W = ix->wsv[w];
+        W.for_each_buffer([](auto& buf) { buf.release(); });
+        if (W.h_flags) (void)hipHostFree(W.h_flags);
+        if (w == 1 && W.stream) { (void)hipStreamSynchronize(W.stream); (void)hipStreamDestroy(W.stream); }
+    }
+    delete[] ix->wsv;
     if (ix->h_pairs) (void)hipHostFree(ix->h_pairs);
     if (ix->h_pout) (void)hipHostFree(ix->h_pout);
     if (ix->ev0) { (void)hipEventDestroy(ix->ev0); (void)hipEventDestroy(ix->ev1); }
@@ -1202,6 +1239,7 @@ int vdb_flat_add(vdb_flat_index* ix, uint64_t id, const float* v, size_t dim) {
     return guarded([&]() -> int {
     if (!ix || (!v && dim)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
+    if (in_flight(ix)) return refuse_in_flight();
     int rc = set_device(ix);
     if (rc) return rc;
     return add_one(ix, id, v, dim);
@@ -1213,6 +1251,7 @@ int vdb_flat_add_bulk(vdb_flat_index* ix, const uint64_t* ids, uint64_t first_id
     return guarded([&]() -> int {
     if (!ix || (!rows && n && dim)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
+    if (in_flight(ix)) return refuse_in_flight();
     int rc = set_device(ix);
     if (rc) return rc;
     if (ix->n_rows() + n > 0xfffffff0ull) return fail(VDB_ERR_INVALID_ARGUMENT, "more than 2^32 rows per index");
@@ -1236,6 +1275,7 @@ int vdb_flat_add_bulk_device(vdb_flat_index* ix, const uint64_t* ids, uint64_t f
     if (n == 0) return VDB_OK;
     if (dim == 0) return fail(VDB_ERR_INVALID_ARGUMENT, "dim must be > 0");
     std::lock_guard<std::mutex> g(ix->mu);
+    if (in_flight(ix)) return refuse_in_flight();
     int rc = set_device(ix);
     if (rc) return rc;
     if (ix->n_rows() + n > 0xfffffff0ull) return fail(VDB_ERR_INVALID_ARGUMENT, "more than 2^32 rows per index");
@@ -1327,6 +1367,7 @@ int vdb_flat_remove(vdb_flat_index* ix, uint64_t id) {
     return guarded([&]() -> int {
     if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
     std::lock_guard<std::mutex> g(ix->mu);
+    if (in_flight(ix)) return refuse_in_flight();
     int rc = set_device(ix);
     if (rc) return rc;
     return remove_id(ix, id);
@@ -1368,6 +1409,7 @@ int vdb_flat_reserve(vdb_flat_index* ix, size_t rows, size_t dim) {
     return guarded([&]() -> int {
     if (!ix || !dim) return fail(VDB_ERR_INVALID_ARGUMENT, "bad argument");
     std::lock_guard<std::mutex> g(ix->mu);
+    if (in_flight(ix)) return refuse_in_flight();
     int rc = set_device(ix);
     if (rc) return rc;
     if (ix->n_live == 0 && ix->misfits.empty()) {
@@ -1386,6 +1428,7 @@ int vdb_flat_flush(vdb_flat_index* ix) {
     return guarded([&]() -> int {
     if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
     std::lock_guard<std::mutex> g(ix->mu);
+    if (in_flight(ix)) return refuse_in_flight();
     int rc = set_device(ix);
     if (rc) return rc;
     if ((rc = flush(ix))) return rc;
@@ -1414,11 +1457,13 @@ int vdb_flat_search_batch_device_begin(vdb_flat_index* ix, const float* d_querie
         return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     ix->mu.lock();
     if (ix->begin_locked) { ix->mu.unlock(); return fail(VDB_ERR_INVALID_ARGUMENT, "a search is already pending on this handle"); }
+    if (in_flight(ix)) { ix->mu.unlock(); return refuse_in_flight(); }
+    ix->cur = &ix->wsv[0];
     // (the handle is locked by hand here: an exception must not skip the unlock below)
     int rc = guarded([&]() -> int { return search_part1(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts, (hipStream_t)stream); });
     if (rc == VDB_OK && d_code) {
         hipStream_t s = stream ? (hipStream_t)stream : ix->stream;
-        if (ix->ctx.pending) vdb::launch_write_code(ix->w_flags.p, d_code, s);
+        if (ix->cur->ctx.pending) vdb::launch_write_code(ix->cur->w_flags.p, d_code, s);
         else if (hipMemsetAsync(d_code, 0, 4, s) != hipSuccess) rc = fail(VDB_ERR_DEVICE, "hipMemsetAsync failed");
     }
     if (rc == VDB_OK && !stream) {
@@ -1429,8 +1474,8 @@ int vdb_flat_search_batch_device_begin(vdb_flat_index* ix, const float* d_querie
             rc = fail(VDB_ERR_DEVICE, "stream ordering failed");
     }
     if (rc) {
-        if (ix->ctx.pending) (void)hipStreamSynchronize(ix->ctx.s);
-        ix->ctx.pending = false; ix->mu.unlock(); return rc;
+        if (ix->cur->ctx.pending) (void)hipStreamSynchronize(ix->cur->ctx.s);
+        ix->cur->ctx.pending = false; ix->mu.unlock(); return rc;
     }
     ix->begin_locked = true;                                   // released by vdb_flat_search_batch_device_finish (same thread)
     return VDB_OK;
@@ -1442,9 +1487,49 @@ int vdb_flat_search_batch_device_finish(vdb_flat_index* ix, int* changed) {
     if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
     if (!ix->begin_locked) return fail(VDB_ERR_INVALID_ARGUMENT, "no search pending on this handle");
     int rc = guarded([&]() -> int { return search_part2(ix, changed); });
-    ix->ctx.pending = false;
+    publish_stats(ix);
+    ix->cur->ctx.pending = false;
     ix->begin_locked = false;
     ix->mu.unlock();
+    return rc;
+    });
+}
+
+int vdb_flat_search_batch_device_submit(vdb_flat_index* ix, const float* d_queries, size_t nq, size_t dim, size_t k,
+                                        const uint64_t* d_id_mask, size_t mask_bits, uint64_t* d_out_ids, float* d_out_dists,
+                                        uint32_t* d_out_counts, void* stream, int* ticket) {
+    return guarded([&]() -> int {
+    if (!ix || !ticket || (nq && (!d_queries || !d_out_counts || (k && (!d_out_ids || !d_out_dists)))))
+        return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    *ticket = -1;
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (ix->begin_locked) return fail(VDB_ERR_INVALID_ARGUMENT, "a search is pending between begin and finish");
+    if (ix->profile) return fail(VDB_ERR_INVALID_ARGUMENT, "kernel profiling synchronises inside the search: not available for submitted searches");
+    int slot = !ix->wsv[0].busy ? 0 : (!ix->wsv[1].busy ? 1 : -1);
+    if (slot < 0) return fail(VDB_ERR_INVALID_ARGUMENT, "two searches are already in flight on this handle");
+    ix->cur = &ix->wsv[slot];
+    int rc = search_part1(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts, (hipStream_t)stream);
+    if (rc) { ix->cur->ctx.pending = false; ix->cur = &ix->wsv[0]; return rc; }
+    ix->cur->busy = true;                       // (a search part 1 answered completely has pending = false: wait() returns at once)
+    ix->cur = &ix->wsv[0];
+    *ticket = slot;
+    return VDB_OK;
+    });
+}
+
+int vdb_flat_search_batch_device_wait(vdb_flat_index* ix, int ticket) {
+    return guarded([&]() -> int {
+    if (!ix || ticket < 0 || ticket > 1) return fail(VDB_ERR_INVALID_ARGUMENT, "bad ticket");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (!ix->wsv[ticket].busy) return fail(VDB_ERR_INVALID_ARGUMENT, "no submitted search behind this ticket");
+    int rc = set_device(ix);
+    if (rc) return rc;
+    ix->cur = &ix->wsv[ticket];
+    rc = search_part2(ix, nullptr);
+    publish_stats(ix);
+    ix->cur->ctx.pending = false;
+    ix->cur->busy = false;
+    ix->cur = &ix->wsv[0];
     return rc;
     });
 }
@@ -1462,6 +1547,7 @@ int vdb_flat_search_batch(vdb_flat_index* ix, const float* queries, size_t nq, s
     if (kmax > kstride) return fail(VDB_ERR_INVALID_ARGUMENT, "kstride %zu smaller than the largest k %zu", kstride, kmax);
     if (kmax && nq && (!out_ids || !out_dists)) return fail(VDB_ERR_INVALID_ARGUMENT, "null output");
     std::lock_guard<std::mutex> g(ix->mu);
+    if (in_flight(ix)) return refuse_in_flight();
     int rc = set_device(ix);
     if (rc) return rc;
     if (nq == 0) return VDB_OK;
@@ -1469,28 +1555,28 @@ int vdb_flat_search_batch(vdb_flat_index* ix, const float* queries, size_t nq, s
     size_t len = ix->n_live + ix->misfits.size();
     size_t kdev = std::min(kmax, std::max<size_t>(len, 1));
     hipStream_t s = ix->stream;
-    if ((rc = ix->w_qin.ensure(nq * std::max<size_t>(dim, 1)))) return rc;
-    if ((rc = ix->w_outi.ensure(nq * std::max<size_t>(kdev, 1)))) return rc;
-    if ((rc = ix->w_outd.ensure(nq * std::max<size_t>(kdev, 1)))) return rc;
-    if ((rc = ix->w_outc.ensure(nq))) return rc;
-    if (dim) HIP_TRY(hipMemcpyAsync(ix->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    if ((rc = ix->cur->w_qin.ensure(nq * std::max<size_t>(dim, 1)))) return rc;
+    if ((rc = ix->cur->w_outi.ensure(nq * std::max<size_t>(kdev, 1)))) return rc;
+    if ((rc = ix->cur->w_outd.ensure(nq * std::max<size_t>(kdev, 1)))) return rc;
+    if ((rc = ix->cur->w_outc.ensure(nq))) return rc;
+    if (dim) HIP_TRY(hipMemcpyAsync(ix->cur->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
     const uint64_t* d_mask = nullptr;
     if (id_mask) {
         size_t words = (mask_bits + 63) / 64;
-        if ((rc = ix->w_mask_ids.ensure(std::max<size_t>(words, 1)))) return rc;
-        if (words) HIP_TRY(hipMemcpyAsync(ix->w_mask_ids.p, id_mask, words * 8, hipMemcpyHostToDevice, s));
-        d_mask = ix->w_mask_ids.p;
+        if ((rc = ix->cur->w_mask_ids.ensure(std::max<size_t>(words, 1)))) return rc;
+        if (words) HIP_TRY(hipMemcpyAsync(ix->cur->w_mask_ids.p, id_mask, words * 8, hipMemcpyHostToDevice, s));
+        d_mask = ix->cur->w_mask_ids.p;
     }
-    rc = search_device(ix, ix->w_qin.p, nq, dim, kdev, d_mask, mask_bits, ix->w_outi.p, ix->w_outd.p, ix->w_outc.p,
+    rc = search_device(ix, ix->cur->w_qin.p, nq, dim, kdev, d_mask, mask_bits, ix->cur->w_outi.p, ix->cur->w_outd.p, ix->cur->w_outc.p,
                        nullptr);
     if (rc) return rc;
     std::vector<uint32_t> cnt(nq);
     std::vector<uint64_t> ids(nq * std::max<size_t>(kdev, 1));
     std::vector<float> ds(nq * std::max<size_t>(kdev, 1));
-    HIP_TRY(hipMemcpyAsync(cnt.data(), ix->w_outc.p, nq * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(cnt.data(), ix->cur->w_outc.p, nq * 4, hipMemcpyDeviceToHost, s));
     if (kdev) {
-        HIP_TRY(hipMemcpyAsync(ids.data(), ix->w_outi.p, nq * kdev * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(ds.data(), ix->w_outd.p, nq * kdev * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ids.data(), ix->cur->w_outi.p, nq * kdev * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ds.data(), ix->cur->w_outd.p, nq * kdev * 4, hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(hipStreamSynchronize(s));
     for (size_t b = 0; b < nq; ++b) {
@@ -1536,6 +1622,7 @@ int vdb_flat_distances_batch(vdb_flat_index* ix, const float* queries, size_t nq
     const size_t total = offsets[nq];
     if (total && (!ids || !out_dists)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
+    if (in_flight(ix)) return refuse_in_flight();
     int rc = set_device(ix);
     if (rc) return rc;
     if ((rc = flush(ix))) return rc;
@@ -1557,27 +1644,27 @@ int vdb_flat_distances_batch(vdb_flat_index* ix, const float* queries, size_t nq
             prow[i] = it == ix->id2row.end() ? 0xffffffffu : it->second;
             pq[i] = q;
         }
-    if ((rc = ix->w_qin.ensure(nq * dim))) return rc;
-    if ((rc = ix->w_qp.ensure((size_t)bp * ld))) return rc;
-    if ((rc = ix->w_qnorm.ensure(bp))) return rc;
-    if ((rc = ix->w_thr.ensure(bp))) return rc;
-    if ((rc = ix->w_flags.ensure(4))) return rc;
-    if ((rc = ix->w_rowmask.ensure(2 * total))) return rc;      // pair_row | pair_query
-    if ((rc = ix->w_outd.ensure(total))) return rc;
-    HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, 16, s));
-    HIP_TRY(hipMemcpyAsync(ix->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ix->w_rowmask.p, prow.data(), total * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ix->w_rowmask.p + total, pq.data(), total * 4, hipMemcpyHostToDevice, s));
-    vdb::QueryPrepParams qp{ix->w_qin.p, (uint32_t)dim, nq32, ix->w_qp.p, ld, bp, ix->w_qnorm.p, ix->w_thr.p, vdb::EUCLID,
-                            ix->w_flags.p, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr};   // metric EUCLID here: zero norms are judged per PAIR below
+    if ((rc = ix->cur->w_qin.ensure(nq * dim))) return rc;
+    if ((rc = ix->cur->w_qp.ensure((size_t)bp * ld))) return rc;
+    if ((rc = ix->cur->w_qnorm.ensure(bp))) return rc;
+    if ((rc = ix->cur->w_thr.ensure(bp))) return rc;
+    if ((rc = ix->cur->w_flags.ensure(4))) return rc;
+    if ((rc = ix->cur->w_rowmask.ensure(2 * total))) return rc;      // pair_row | pair_query
+    if ((rc = ix->cur->w_outd.ensure(total))) return rc;
+    HIP_TRY(hipMemsetAsync(ix->cur->w_flags.p, 0, 16, s));
+    HIP_TRY(hipMemcpyAsync(ix->cur->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ix->cur->w_rowmask.p, prow.data(), total * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ix->cur->w_rowmask.p + total, pq.data(), total * 4, hipMemcpyHostToDevice, s));
+    vdb::QueryPrepParams qp{ix->cur->w_qin.p, (uint32_t)dim, nq32, ix->cur->w_qp.p, ld, bp, ix->cur->w_qnorm.p, ix->cur->w_thr.p, vdb::EUCLID,
+                            ix->cur->w_flags.p, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr};   // metric EUCLID here: zero norms are judged per PAIR below
     vdb::launch_query_prep(qp, s);
-    vdb::PairDistParams pp{ix->d_rows, ld, (uint32_t)dim, ix->w_qp.p, ix->w_qnorm.p, ix->d_nd, ix->w_rowmask.p + total,
-                           ix->w_rowmask.p, (uint32_t)total, ix->metric, ix->w_outd.p, ix->w_flags.p};
+    vdb::PairDistParams pp{ix->d_rows, ld, (uint32_t)dim, ix->cur->w_qp.p, ix->cur->w_qnorm.p, ix->d_nd, ix->cur->w_rowmask.p + total,
+                           ix->cur->w_rowmask.p, (uint32_t)total, ix->metric, ix->cur->w_outd.p, ix->cur->w_flags.p};
     vdb::launch_pair_distances(pp, s);
     HIP_TRY(hipGetLastError());
     uint32_t st = 0;
-    HIP_TRY(hipMemcpyAsync(out_dists, ix->w_outd.p, total * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&st, ix->w_flags.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_dists, ix->cur->w_outd.p, total * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&st, ix->cur->w_flags.p, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (st & vdb::ST_ZERO_QUERY)
         return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
@@ -1628,7 +1715,7 @@ int vdb_flat_last_stats(const vdb_flat_index* ix, uint64_t out[8]) {
 int vdb_flat_last_stats_ex(const vdb_flat_index* ix, uint64_t* out, size_t n) {
     return guarded([&]() -> int {
     if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
-    for (size_t i = 0; i < n; ++i) out[i] = i < 16 ? ix->stats[i] : 0;
+    for (size_t i = 0; i < n; ++i) out[i] = i < 16 ? ix->cur->stats[i] : 0;
     return VDB_OK;
     });
 }
@@ -1640,6 +1727,7 @@ int vdb_flat_debug_screen_scores(vdb_flat_index* ix, const float* queries, size_
     if (!ix || !queries || !out_scores || !nq) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     if (nq > SUPER) return fail(VDB_ERR_INVALID_ARGUMENT, "at most %u queries per call", SUPER);
     std::lock_guard<std::mutex> g(ix->mu);
+    if (in_flight(ix)) return refuse_in_flight();
     int rc;
     if ((rc = set_device(ix))) return rc;
     if ((rc = flush(ix))) return rc;
@@ -1655,41 +1743,41 @@ int vdb_flat_debug_screen_scores(vdb_flat_index* ix, const float* queries, size_
     const uint32_t capl = 64u * ((nblk + n_wg - 1) / n_wg);            // every row of a workgroup's range fits its sub-pools
     const size_t pool_keys = (size_t)SUPER * n_sub * capl;
     if (pool_keys * 8 > ((size_t)6 << 30)) return fail(VDB_ERR_INVALID_ARGUMENT, "index too large for the score dump");
-    if ((rc = ix->w_qin.ensure(nq * dim))) return rc;
-    if ((rc = ix->w_qp.ensure((size_t)SUPER * ld))) return rc;
-    if ((rc = ix->w_qnorm.ensure(SUPER))) return rc;
-    if ((rc = ix->w_thr.ensure(SUPER))) return rc;
-    if ((rc = ix->w_qb.ensure((size_t)SUPER * ld))) return rc;
-    if ((rc = ix->w_qerr.ensure(SUPER))) return rc;
-    if ((rc = ix->w_qg.ensure(SUPER))) return rc;
-    if ((rc = ix->w_flags.ensure(4 + 3 * (size_t)SUPER))) return rc;
-    if ((rc = ix->w_pool.ensure(pool_keys))) return rc;
-    if ((rc = ix->w_subcnt.ensure((size_t)SUPER * n_sub))) return rc;
-    if ((rc = ix->w_dbg.ensure(nq * (size_t)n))) return rc;
-    ix->status_dirty = true;
-    HIP_TRY(hipMemsetAsync(ix->w_flags.p, 0, 16, s));
-    HIP_TRY(hipMemcpyAsync(ix->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    if ((rc = ix->cur->w_qin.ensure(nq * dim))) return rc;
+    if ((rc = ix->cur->w_qp.ensure((size_t)SUPER * ld))) return rc;
+    if ((rc = ix->cur->w_qnorm.ensure(SUPER))) return rc;
+    if ((rc = ix->cur->w_thr.ensure(SUPER))) return rc;
+    if ((rc = ix->cur->w_qb.ensure((size_t)SUPER * ld))) return rc;
+    if ((rc = ix->cur->w_qerr.ensure(SUPER))) return rc;
+    if ((rc = ix->cur->w_qg.ensure(SUPER))) return rc;
+    if ((rc = ix->cur->w_flags.ensure(4 + 3 * (size_t)SUPER))) return rc;
+    if ((rc = ix->cur->w_pool.ensure(pool_keys))) return rc;
+    if ((rc = ix->cur->w_subcnt.ensure((size_t)SUPER * n_sub))) return rc;
+    if ((rc = ix->cur->w_dbg.ensure(nq * (size_t)n))) return rc;
+    ix->cur->status_dirty = true;
+    HIP_TRY(hipMemsetAsync(ix->cur->w_flags.p, 0, 16, s));
+    HIP_TRY(hipMemcpyAsync(ix->cur->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
     const bool lb = ix->d_margin && !raw;
-    vdb::QueryPrepParams qp{ix->w_qin.p, (uint32_t)dim, (uint32_t)nq, ix->w_qp.p, ld, SUPER, ix->w_qnorm.p, ix->w_thr.p, vdb::EUCLID,
-                            ix->w_flags.p, ix->w_qb.p, ix->w_qerr.p, ix->d_margin ? ix->w_qg.p : nullptr, margin_plan(ix).kappa,
+    vdb::QueryPrepParams qp{ix->cur->w_qin.p, (uint32_t)dim, (uint32_t)nq, ix->cur->w_qp.p, ld, SUPER, ix->cur->w_qnorm.p, ix->cur->w_thr.p, vdb::EUCLID,
+                            ix->cur->w_flags.p, ix->cur->w_qb.p, ix->cur->w_qerr.p, ix->d_margin ? ix->cur->w_qg.p : nullptr, margin_plan(ix).kappa,
                             nullptr, nullptr};
     vdb::launch_query_prep(qp, s);
     std::vector<float> thr(nq, std::numeric_limits<float>::infinity());            // everything passes; padding queries keep -inf
-    HIP_TRY(hipMemcpyAsync(ix->w_thr.p, thr.data(), nq * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(ix->w_dbg.p, 0xff, nq * (size_t)n * 4, s));            // NaN pattern = no key for this (query, row)
+    HIP_TRY(hipMemcpyAsync(ix->cur->w_thr.p, thr.data(), nq * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(ix->cur->w_dbg.p, 0xff, nq * (size_t)n * 4, s));            // NaN pattern = no key for this (query, row)
     vdb::FusedBf16Params fp{};
-    fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->w_qb.p; fp.alpha = ix->d_alpha; fp.beta = ix->d_beta;
-    fp.margin = lb ? ix->d_margin : nullptr; fp.qg = lb ? ix->w_qg.p : nullptr;
-    fp.rowmask = ix->d_live; fp.thr = ix->w_thr.p; fp.pool = ix->w_pool.p; fp.pool_cnt = ix->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
+    fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->cur->w_qb.p; fp.alpha = ix->d_alpha; fp.beta = ix->d_beta;
+    fp.margin = lb ? ix->d_margin : nullptr; fp.qg = lb ? ix->cur->w_qg.p : nullptr;
+    fp.rowmask = ix->d_live; fp.thr = ix->cur->w_thr.p; fp.pool = ix->cur->w_pool.p; fp.pool_cnt = ix->cur->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
     vdb::launch_fused_bf16p(fp, s);                                              // the PRODUCTION filter pass
-    vdb::launch_pool_to_dense(ix->w_pool.p, ix->w_subcnt.p, n_sub, capl, (uint32_t)nq, n, ix->w_dbg.p, s);
+    vdb::launch_pool_to_dense(ix->cur->w_pool.p, ix->cur->w_subcnt.p, n_sub, capl, (uint32_t)nq, n, ix->cur->w_dbg.p, s);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out_scores, ix->w_dbg.p, nq * (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_scores, ix->cur->w_dbg.p, nq * (size_t)n * 4, hipMemcpyDeviceToHost, s));
     std::vector<float> qn(nq), qe(nq), qg(nq, 0.0f);
     uint32_t sc[8] = {0};
-    HIP_TRY(hipMemcpyAsync(qn.data(), ix->w_qnorm.p, nq * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(qe.data(), ix->w_qerr.p, nq * 4, hipMemcpyDeviceToHost, s));
-    if (ix->d_margin) HIP_TRY(hipMemcpyAsync(qg.data(), ix->w_qg.p, nq * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(qn.data(), ix->cur->w_qnorm.p, nq * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(qe.data(), ix->cur->w_qerr.p, nq * 4, hipMemcpyDeviceToHost, s));
+    if (ix->d_margin) HIP_TRY(hipMemcpyAsync(qg.data(), ix->cur->w_qg.p, nq * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(sc, ix->d_scalars, 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (out_qinfo)
@@ -1701,7 +1789,7 @@ int vdb_flat_debug_screen_scores(vdb_flat_index* ix, const float* queries, size_
         out_consts[3] = std::sqrt(f(sc[0])); out_consts[4] = std::sqrt(f(sc[2])); out_consts[5] = std::sqrt(f(sc[3]));   // max |d|, max |e_d|, max |e_d|/|d|
         out_consts[6] = lb ? 1.0 : 0.0; out_consts[7] = (double)ld;
     }
-    ix->dbg_nq = (uint32_t)nq; ix->dbg_lb = lb;
+    ix->cur->dbg_nq = (uint32_t)nq; ix->cur->dbg_lb = lb;
     return VDB_OK;
     });
 }
@@ -1712,6 +1800,7 @@ int vdb_flat_debug_row_info(vdb_flat_index* ix, float* out, size_t n_rows) {
     return guarded([&]() -> int {
     if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
+    if (in_flight(ix)) return refuse_in_flight();
     int rc;
     if ((rc = set_device(ix))) return rc;
     if ((rc = flush(ix))) return rc;
@@ -1732,13 +1821,14 @@ int vdb_flat_debug_cert_probe(vdb_flat_index* ix, const uint32_t* qi, const floa
     return guarded([&]() -> int {
     if (!ix || !qi || !T || !ek || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
+    if (in_flight(ix)) return refuse_in_flight();
     int rc;
     if ((rc = set_device(ix))) return rc;
-    if (!ix->dbg_nq) return fail(VDB_ERR_INVALID_ARGUMENT, "call vdb_flat_debug_screen_scores first");
+    if (!ix->cur->dbg_nq) return fail(VDB_ERR_INVALID_ARGUMENT, "call vdb_flat_debug_screen_scores first");
     if (n == 0) return VDB_OK;
     if (n > 0x7fffffffull) return fail(VDB_ERR_INVALID_ARGUMENT, "too many probes");
     for (size_t i = 0; i < n; ++i)
-        if (qi[i] >= ix->dbg_nq) return fail(VDB_ERR_INVALID_ARGUMENT, "query index %u out of range", qi[i]);
+        if (qi[i] >= ix->cur->dbg_nq) return fail(VDB_ERR_INVALID_ARGUMENT, "query index %u out of range", qi[i]);
     hipStream_t s = ix->stream;
     DevBuf<uint32_t> d_qi, d_out; DevBuf<float> d_T, d_ek;
     auto done = [&](int r) { d_qi.release(); d_out.release(); d_T.release(); d_ek.release(); return r; };
@@ -1748,8 +1838,8 @@ int vdb_flat_debug_cert_probe(vdb_flat_index* ix, const uint32_t* qi, const floa
         return done(fail(VDB_ERR_DEVICE, "copy failed"));
     // the same parameter block the screening tier's re-rank gets (pass_bf16)
     vdb::RerankParams rp{};
-    rp.metric = ix->metric; rp.eps_coef = eps_coef(ix); rp.nd2max_bits = ix->d_scalars; rp.qnorm = ix->w_qnorm.p; rp.ld = ix->ld;
-    rp.qerr = ix->w_qerr.p; rp.c_acc = c_acc_bf16(ix); rp.lb_scores = ix->dbg_lb ? 1u : 0u;
+    rp.metric = ix->metric; rp.eps_coef = eps_coef(ix); rp.nd2max_bits = ix->d_scalars; rp.qnorm = ix->cur->w_qnorm.p; rp.ld = ix->ld;
+    rp.qerr = ix->cur->w_qerr.p; rp.c_acc = c_acc_bf16(ix); rp.lb_scores = ix->cur->dbg_lb ? 1u : 0u;
     vdb::launch_cert_probe(rp, d_qi.p, d_T.p, d_ek.p, (uint32_t)n, d_out.p, s);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d_out.p, n * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)
@@ -1801,6 +1891,7 @@ static int ensure_pair_buffers(vdb_flat_index* ix, size_t n_pairs, size_t n_out)
 
 int pairs_begin(vdb_flat_index* ix, const float* queries, size_t nq, size_t dim) {
     std::lock_guard<std::mutex> g(ix->mu);
+    if (ix->wsv && (ix->wsv[0].busy || ix->wsv[1].busy)) return fail(VDB_ERR_INVALID_ARGUMENT, "a submitted search is still in flight on this handle");
     int rc;
     if ((rc = set_device(ix))) return rc;
     if ((rc = flush(ix))) return rc;
@@ -1811,14 +1902,14 @@ int pairs_begin(vdb_flat_index* ix, const float* queries, size_t nq, size_t dim)
     const uint32_t ld = ix->ld ? ix->ld : round_up((uint32_t)dim, vdb::KSTAGE);
     const uint32_t bp = round_up((uint32_t)nq, SUPER);
     hipStream_t s = ix->stream;
-    if ((rc = ix->w_qin.ensure(nq * dim))) return rc;
-    if ((rc = ix->w_qp.ensure((size_t)bp * ld))) return rc;
-    if ((rc = ix->w_qnorm.ensure(bp))) return rc;
-    if ((rc = ix->w_thr.ensure(bp))) return rc;
-    if ((rc = ix->w_flags.ensure(4))) return rc;
-    HIP_TRY(hipMemcpyAsync(ix->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
-    vdb::QueryPrepParams qp{ix->w_qin.p, (uint32_t)dim, (uint32_t)nq, ix->w_qp.p, ld, bp, ix->w_qnorm.p, ix->w_thr.p, vdb::EUCLID,
-                            ix->w_flags.p, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr};   // metric EUCLID: zero norms are judged per pair
+    if ((rc = ix->cur->w_qin.ensure(nq * dim))) return rc;
+    if ((rc = ix->cur->w_qp.ensure((size_t)bp * ld))) return rc;
+    if ((rc = ix->cur->w_qnorm.ensure(bp))) return rc;
+    if ((rc = ix->cur->w_thr.ensure(bp))) return rc;
+    if ((rc = ix->cur->w_flags.ensure(4))) return rc;
+    HIP_TRY(hipMemcpyAsync(ix->cur->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    vdb::QueryPrepParams qp{ix->cur->w_qin.p, (uint32_t)dim, (uint32_t)nq, ix->cur->w_qp.p, ld, bp, ix->cur->w_qnorm.p, ix->cur->w_thr.p, vdb::EUCLID,
+                            ix->cur->w_flags.p, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr};   // metric EUCLID: zero norms are judged per pair
     vdb::launch_query_prep(qp, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
@@ -1828,6 +1919,7 @@ int pairs_begin(vdb_flat_index* ix, const float* queries, size_t nq, size_t dim)
 
 static int run_pair_eval(vdb_flat_index* ix, int mode, const uint32_t* a, const uint32_t* b, uint32_t q0, size_t n, float* out) {
     std::lock_guard<std::mutex> g(ix->mu);
+    if (ix->wsv && (ix->wsv[0].busy || ix->wsv[1].busy)) return fail(VDB_ERR_INVALID_ARGUMENT, "a submitted search is still in flight on this handle");
     int rc;
     if ((rc = set_device(ix))) return rc;
     if (n == 0) return VDB_OK;
@@ -1842,7 +1934,7 @@ static int run_pair_eval(vdb_flat_index* ix, int mode, const uint32_t* a, const 
         memcpy(ix->h_pairs + n, b, n * sizeof(uint32_t));
     }
     vdb::PairEvalParams pp{};
-    pp.rows = ix->d_rows; pp.ld = ix->ld; pp.dim = ix->dim; pp.nd = ix->d_nd; pp.qp = ix->w_qp.p; pp.qnorm = ix->w_qnorm.p;
+    pp.rows = ix->d_rows; pp.ld = ix->ld; pp.dim = ix->dim; pp.nd = ix->d_nd; pp.qp = ix->cur->w_qp.p; pp.qnorm = ix->cur->w_qnorm.p;
     pp.a = d_pairs; pp.b = d_pairs + n; pp.n = (uint32_t)n; pp.q0 = q0; pp.mode = mode; pp.metric = ix->metric;
     pp.mark = ZERO_NORM_MARK; pp.out = d_out;
     vdb::launch_pair_eval(pp, ix->stream);
@@ -1872,9 +1964,9 @@ int device_view(vdb_flat_index* ix, DeviceView* out) {
     std::lock_guard<std::mutex> g(ix->mu);
     int rc;
     if ((rc = set_device(ix))) return rc;
-    if ((rc = ix->w_flags.ensure(4))) return rc;
-    out->rows = ix->d_rows; out->ld = ix->ld; out->dim = ix->dim; out->nd = ix->d_nd; out->qp = ix->w_qp.p; out->qnorm = ix->w_qnorm.p;
-    out->metric = ix->metric; out->stream = (void*)ix->stream; out->status = ix->w_flags.p;
+    if ((rc = ix->cur->w_flags.ensure(4))) return rc;
+    out->rows = ix->d_rows; out->ld = ix->ld; out->dim = ix->dim; out->nd = ix->d_nd; out->qp = ix->cur->w_qp.p; out->qnorm = ix->cur->w_qnorm.p;
+    out->metric = ix->metric; out->stream = (void*)ix->stream; out->status = ix->cur->w_flags.p;
     return VDB_OK;
 }
 int set_error(int code, const char* msg) { return fail(code, "%s", msg); }

@@ -239,6 +239,24 @@ class GpuFlatIndex(Index):
             _raise(rc)
         return bool(changed.value)
 
+    def search_batch_device_submit(self, q_ptr, nq, dim, k, out_ids_ptr, out_dists_ptr, out_counts_ptr, stream=0,
+                                   mask_ptr=0, mask_bits=0):
+        """Asynchronous form: the first tier is enqueued, a ticket comes back at once; at most two tickets per handle."""
+        t = ctypes.c_int(-1)
+        rc = self._L.vdb_flat_search_batch_device_submit(
+            self._h, ctypes.c_void_p(q_ptr), int(nq), int(dim), int(k), ctypes.c_void_p(mask_ptr or None),
+            int(mask_bits), ctypes.c_void_p(out_ids_ptr), ctypes.c_void_p(out_dists_ptr),
+            ctypes.c_void_p(out_counts_ptr), ctypes.c_void_p(stream or None), ctypes.byref(t))
+        if rc:
+            _raise(rc)
+        return t.value
+
+    def search_batch_device_wait(self, ticket):
+        """Waits for a submitted search, runs its fallback tiers where needed; its outputs are complete on return."""
+        rc = self._L.vdb_flat_search_batch_device_wait(self._h, int(ticket))
+        if rc:
+            _raise(rc)
+
     def distances_batch(self, queries, id_lists):
         """Exact reference distances of query b to the stored ids id_lists[b] (HNSW candidate lists)."""
         qs = np.ascontiguousarray(queries, dtype=np.float32)
