@@ -375,9 +375,21 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
             float best_a = __uint_as_float(0x7f800000u), best_b = best_a;   // sample mode: running group minima
             const float* al = sAlpha + par * TR + wr * 128 + 4 * h;
             const float* be = sBeta + par * TR + wr * 128 + 4 * h;
-            const float* mg = sMarg + (MARGIN ? par * TR + wr * 128 + 4 * h : 0);
-            f32x2 ng_a = {0.f, 0.f}, ng_b = {0.f, 0.f};
-            if (MARGIN) { const float ga = -sG[q_a], gb = -sG[q_b]; ng_a = f32x2{ga, ga}; ng_b = f32x2{gb, gb}; }
+            // MARGIN: the filter is  lb = fma(-g_q, margin_row, score) <= thr.  Since margin_row <= mmax (the largest margin of
+            // this wave's 128 rows), lb <= thr implies score <= thr + g_q mmax =: thp -- so the COMMON path compares the plain
+            // score with a per-tile loosened threshold (two fmas per lane and tile instead of one packed fma and one more LDS
+            // read per pair of elements), and only the rare path computes lb and applies the exact test.  The slack covers
+            // the f32 rounding of thp and of lb, so no row with lb <= thr can fail the pre-test.
+            const float* mg = sMarg + (MARGIN ? par * TR + wr * 128 : 0);
+            float thp_a = thr_a, thp_b = thr_b, ng_a = 0.f, ng_b = 0.f;
+            if (MARGIN) {
+                float mm = fmaxf(mg[2 * lane], mg[2 * lane + 1]);       // +inf margins (norm overflow) open the tile; NaN rows carry NaN scores anyway
+                for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o));
+                const float ga = sG[q_a], gb = sG[q_b];
+                ng_a = -ga; ng_b = -gb;
+                thp_a = fmaf(ga, mm, thr_a); thp_a += (fabsf(thr_a) + ga * mm) * 6.0e-7f;
+                thp_b = fmaf(gb, mm, thr_b); thp_b += (fabsf(thr_b) + gb * mm) * 6.0e-7f;
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const uint32_t vbits = (uint32_t)(val[i >> 1] >> (32 * (i & 1) + 4 * h));
@@ -391,14 +403,8 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
                     const f32x2 al01 = {a4.x, a4.y}, al23 = {a4.z, a4.w}, be01 = {b4.x, b4.y}, be23 = {b4.z, b4.w};
                     const f32x2 pa01 = {acc[i][0][4 * j + 0], acc[i][0][4 * j + 1]}, pa23 = {acc[i][0][4 * j + 2], acc[i][0][4 * j + 3]};
                     const f32x2 pb01 = {acc[i][1][4 * j + 0], acc[i][1][4 * j + 1]}, pb23 = {acc[i][1][4 * j + 2], acc[i][1][4 * j + 3]};
-                    f32x2 ra01 = __builtin_elementwise_fma(pa01, al01, be01), ra23 = __builtin_elementwise_fma(pa23, al23, be23);
-                    f32x2 rb01 = __builtin_elementwise_fma(pb01, al01, be01), rb23 = __builtin_elementwise_fma(pb23, al23, be23);
-                    if (MARGIN) {
-                        const float4 m4 = *reinterpret_cast<const float4*>(mg + i * 32 + 8 * j);
-                        const f32x2 m01 = {m4.x, m4.y}, m23 = {m4.z, m4.w};
-                        ra01 = __builtin_elementwise_fma(ng_a, m01, ra01); ra23 = __builtin_elementwise_fma(ng_a, m23, ra23);
-                        rb01 = __builtin_elementwise_fma(ng_b, m01, rb01); rb23 = __builtin_elementwise_fma(ng_b, m23, rb23);
-                    }
+                    const f32x2 ra01 = __builtin_elementwise_fma(pa01, al01, be01), ra23 = __builtin_elementwise_fma(pa23, al23, be23);
+                    const f32x2 rb01 = __builtin_elementwise_fma(pb01, al01, be01), rb23 = __builtin_elementwise_fma(pb23, al23, be23);
                     const float sa0 = ra01.x, sa1 = ra01.y, sa2 = ra23.x, sa3 = ra23.y;
                     const float sb0 = rb01.x, sb1 = rb01.y, sb2 = rb23.x, sb3 = rb23.y;
                     const uint32_t rt0 = rowb + 8 * j;                  // tile-row of element 0
@@ -418,21 +424,25 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
                         // Hits are rare (about 0.2 % of the elements).  Common path per query: four compares whose
                         // lane masks are OR-ed on the scalar unit and ONE not-taken branch; the append code is out of
                         // line.  `!(s > thr)` keeps a NaN score (it must reach the re-rank, flat_index.rs:62).
-                        const unsigned long long ma = __builtin_amdgcn_ballot_w64(!(sa0 > thr_a)) | __builtin_amdgcn_ballot_w64(!(sa1 > thr_a)) |
-                                                      __builtin_amdgcn_ballot_w64(!(sa2 > thr_a)) | __builtin_amdgcn_ballot_w64(!(sa3 > thr_a));
-                        const unsigned long long mb = __builtin_amdgcn_ballot_w64(!(sb0 > thr_b)) | __builtin_amdgcn_ballot_w64(!(sb1 > thr_b)) |
-                                                      __builtin_amdgcn_ballot_w64(!(sb2 > thr_b)) | __builtin_amdgcn_ballot_w64(!(sb3 > thr_b));
+                        const unsigned long long ma = __builtin_amdgcn_ballot_w64(!(sa0 > thp_a)) | __builtin_amdgcn_ballot_w64(!(sa1 > thp_a)) |
+                                                      __builtin_amdgcn_ballot_w64(!(sa2 > thp_a)) | __builtin_amdgcn_ballot_w64(!(sa3 > thp_a));
+                        const unsigned long long mb = __builtin_amdgcn_ballot_w64(!(sb0 > thp_b)) | __builtin_amdgcn_ballot_w64(!(sb1 > thp_b)) |
+                                                      __builtin_amdgcn_ballot_w64(!(sb2 > thp_b)) | __builtin_amdgcn_ballot_w64(!(sb3 > thp_b));
                         // The append path is what the epilogue costs (with thresholds that let nothing pass the kernel is as
                         // fast as without an epilogue), so it is kept short: one 4-bit hit mask per lane and query, then a
                         // loop over its set bits -- typically one lane, one iteration -- instead of four masked regions.
-#define VDB_APPEND(S0, S1, S2, S3, THR, POOL, PCNT)                                                    \
+#define VDB_APPEND(S0, S1, S2, S3, THP, THR, NG, POOL, PCNT)                                           \
     {                                                                                                  \
-        uint32_t hm_ = (!((S0) > (THR)) ? 1u : 0u) | (!((S1) > (THR)) ? 2u : 0u) | (!((S2) > (THR)) ? 4u : 0u) | (!((S3) > (THR)) ? 8u : 0u); \
+        uint32_t hm_ = (!((S0) > (THP)) ? 1u : 0u) | (!((S1) > (THP)) ? 2u : 0u) | (!((S2) > (THP)) ? 4u : 0u) | (!((S3) > (THP)) ? 8u : 0u); \
         hm_ &= (vbits >> (8 * j)) & 0xfu;                                                              \
         while (hm_) {                                                                                  \
             const uint32_t e_ = (uint32_t)__builtin_ctz(hm_);                                          \
             hm_ &= hm_ - 1u;                                                                           \
-            const float sc_ = e_ == 0 ? (S0) : e_ == 1 ? (S1) : e_ == 2 ? (S2) : (S3);                 \
+            float sc_ = e_ == 0 ? (S0) : e_ == 1 ? (S1) : e_ == 2 ? (S2) : (S3);                       \
+            if (MARGIN) {                                              /* the exact test, on the lower-bound score */ \
+                sc_ = fmaf((NG), mg[i * 32 + 8 * j + 4 * h + e_], sc_);                                \
+                if (sc_ > (THR)) continue;                                                             \
+            }                                                                                          \
             if (!(kDiag && (p.ablate & 32u)) && PCNT < p.capl) POOL[PCNT] = make_raw_key(sc_, tr0 + rt0 + e_); /* diag 32: count only */ \
             ++PCNT;                                                                                    \
         }                                                                                              \
@@ -441,8 +451,8 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
                             if (__builtin_expect(ma != 0ull, 0)) { asm volatile("s_nop 1" ::: "memory"); ++pcnt_a; }
                             if (__builtin_expect(mb != 0ull, 0)) { asm volatile("s_nop 1" ::: "memory"); ++pcnt_b; }
                         } else {
-                        if (__builtin_expect(ma != 0ull, 0)) VDB_APPEND(sa0, sa1, sa2, sa3, thr_a, pool_a, pcnt_a)
-                        if (__builtin_expect(mb != 0ull, 0)) VDB_APPEND(sb0, sb1, sb2, sb3, thr_b, pool_b, pcnt_b)
+                        if (__builtin_expect(ma != 0ull, 0)) VDB_APPEND(sa0, sa1, sa2, sa3, thp_a, thr_a, ng_a, pool_a, pcnt_a)
+                        if (__builtin_expect(mb != 0ull, 0)) VDB_APPEND(sb0, sb1, sb2, sb3, thp_b, thr_b, ng_b, pool_b, pcnt_b)
                         }
 #undef VDB_APPEND
                     }
