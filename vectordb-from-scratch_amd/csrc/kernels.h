@@ -306,6 +306,15 @@ struct PairEvalParams {
     float* out;
 };
 void launch_pair_eval(const PairEvalParams& p, hipStream_t s);
+// HNSW build: exact reference distances of up to 16 STORED rows (the vectors being inserted) against device rows
+// [0, n_scan) in ONE pass over the rows -- out[j * ldm + r] = distance(row qrow[j], row r); zero-norm Cosine pairs are
+// written as `mark`.  `out` may live in mapped host memory.
+struct ScanRowsParams {
+    const float* rows; uint32_t ld; uint32_t dim; const float* nd; int metric; uint32_t mark;
+    uint32_t nq; uint32_t qrow[16];
+    uint32_t n_scan; float* out; size_t ldm;
+};
+void launch_scan_rows(const ScanRowsParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------- certificate diagnostics (vdb_flat_debug_*)
 // dense[q*n_rows + row] = score bits of every key the filter pass wrote for query q (wg-major pools of the bf16 tier)

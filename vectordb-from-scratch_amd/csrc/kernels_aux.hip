@@ -1332,6 +1332,86 @@ void launch_pair_eval(const PairEvalParams& p, hipStream_t s) {
     hipLaunchKernelGGL(pair_eval_kernel, dim3((p.n + 255) / 256), dim3(256), 0, s, p);
 }
 
+// One pass over rows [0, n_scan) for up to 16 query rows: one thread per row, the row read once (16 floats at a time)
+// and folded against every query in the reference's order (independent chains -> ILP); the query elements come through
+// scalar loads (uniform addresses).  The all-pairs scan the batched HNSW build amortises over a chunk of inserts.
+template <int NQ>
+__global__ __launch_bounds__(256) void scan_rows_kernel(ScanRowsParams p) {
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= p.n_scan) return;
+    const float* x = p.rows + (size_t)row * p.ld;
+    float s[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) s[j] = 0.0f;
+    const uint32_t d = p.dim;
+    uint32_t i = 0;
+    for (; i + 16 <= d; i += 16) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(x + i + 4 * u);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (j < (int)p.nq) {                                            // wave-uniform
+                const float* q = p.rows + (size_t)p.qrow[j] * p.ld + i;     // uniform address: scalar loads
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 a = *reinterpret_cast<const float4*>(q + 4 * u);
+                    if (p.metric == EUCLID) {
+                        float t;
+                        t = __fsub_rn(a.x, v[u].x); s[j] = __fadd_rn(s[j], __fmul_rn(t, t));
+                        t = __fsub_rn(a.y, v[u].y); s[j] = __fadd_rn(s[j], __fmul_rn(t, t));
+                        t = __fsub_rn(a.z, v[u].z); s[j] = __fadd_rn(s[j], __fmul_rn(t, t));
+                        t = __fsub_rn(a.w, v[u].w); s[j] = __fadd_rn(s[j], __fmul_rn(t, t));
+                    } else {
+                        s[j] = __fadd_rn(s[j], __fmul_rn(a.x, v[u].x));
+                        s[j] = __fadd_rn(s[j], __fmul_rn(a.y, v[u].y));
+                        s[j] = __fadd_rn(s[j], __fmul_rn(a.z, v[u].z));
+                        s[j] = __fadd_rn(s[j], __fmul_rn(a.w, v[u].w));
+                    }
+                }
+            }
+        }
+    }
+    for (; i < d; ++i) {
+        const float xv = x[i];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (j < (int)p.nq) {
+                const float a = p.rows[(size_t)p.qrow[j] * p.ld + i];
+                if (p.metric == EUCLID) { float t = __fsub_rn(a, xv); s[j] = __fadd_rn(s[j], __fmul_rn(t, t)); }
+                else s[j] = __fadd_rn(s[j], __fmul_rn(a, xv));
+            }
+        }
+    }
+    const float xn = p.nd[row];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        if (j < (int)p.nq) {
+            float dist;
+            if (p.metric == EUCLID) dist = __builtin_sqrtf(s[j]);
+            else if (p.metric == DOT) dist = -s[j];
+            else {
+                const float qn = p.nd[p.qrow[j]];
+                if (qn == 0.0f || xn == 0.0f) dist = __uint_as_float(p.mark);
+                else {
+                    float sim = __fdiv_rn(s[j], __fmul_rn(qn, xn));          // norm1 * norm2 with the QUERY's norm first (distance.rs:58)
+                    if (sim < -1.0f) sim = -1.0f;
+                    if (sim > 1.0f) sim = 1.0f;
+                    dist = __fsub_rn(1.0f, sim);
+                }
+            }
+            p.out[(size_t)j * p.ldm + row] = dist;
+        }
+    }
+}
+void launch_scan_rows(const ScanRowsParams& p, hipStream_t s) {
+    if (!p.n_scan || !p.nq) return;
+    const dim3 grid((p.n_scan + 255) / 256), block(256);
+    if (p.nq <= 4) hipLaunchKernelGGL(scan_rows_kernel<4>, grid, block, 0, s, p);
+    else if (p.nq <= 8) hipLaunchKernelGGL(scan_rows_kernel<8>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(scan_rows_kernel<16>, grid, block, 0, s, p);
+}
+
 __global__ void write_code_kernel(const uint32_t* flags, int32_t* code) { *code = (flags[0] | flags[1]) ? 100 : 0; }
 void launch_write_code(const uint32_t* flags, int32_t* code, hipStream_t s) {
     hipLaunchKernelGGL(write_code_kernel, dim3(1), dim3(1), 0, s, flags, code);

@@ -6,8 +6,13 @@
 // unvisited neighbours of all of them as (query, row) pairs, evaluates the whole list in one launch, and feeds the
 // distances back in list order.  Each query sees exactly the sequence of heap operations the reference performs, so
 // results are identical to a CPU run on the same graph; only the waiting is shared.
-// Insert: one exact scan of the new vector against the rows already stored (one launch) answers every distance the
-// sequential insert asks for; the prunes of one layer (graph.rs:207-241) are evaluated as one (row, row) batch.
+// Insert: inserts are sequential by definition (each walks the graph the previous one left), and a GPU round trip per
+// neighbour expansion (graph.rs:182: at most 32 distances) costs ~40 us -- 200 expansions would be 8 ms per insert.  So
+// the distances are produced AHEAD of the walks, amortised over a chunk of inserts: one pass over the stored rows gives
+// the exact distances of 16 new vectors at once (scan_rows_kernel; 128 vectors per chunk, the next chunk's scan and its
+// transfer run while the host walks the current one), and the walks read them from pinned host memory -- no GPU round
+// trip per insert at all.  Prune distances (graph.rs:207-241) are never recomputed: every edge keeps the distance it was
+// created with (d(a,b) and d(b,a) are the same bits under all three metrics).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -104,6 +109,7 @@ struct Node {                                                     // graph.rs:63
     bool present = false;
     uint32_t level = 0, row = 0xffffffffu;
     std::vector<std::vector<uint64_t>> nbr;
+    std::vector<std::vector<float>> nbr_d;                        // nbr_d[l][i] = distance(this node, nbr[l][i]) as evaluated when the edge was made
 };
 
 constexpr float F32_MAX = 3.40282347e+38f;
@@ -130,6 +136,9 @@ struct vdb_hnsw_index {
     size_t out_cap = 0, out_nq_cap = 0;
     uint32_t mirror_ids = 0, stride0 = 0, strideU = 0, max_list = 0;
     uint64_t device_queries = 0, host_redone = 0;
+    // batched insert scans: two mapped host matrices [SCAN_CHUNK][scan_ld] the scan kernel writes, a stream and events
+    float* h_scan[2] = {nullptr, nullptr}; float* d_scan[2] = {nullptr, nullptr}; size_t scan_ld = 0;
+    hipStream_t scan_stream = nullptr; hipEvent_t scan_ev[2] = {nullptr, nullptr};
     bool host_only = false; size_t host_threads = 0;              // vdb_hnsw_set_traversal
     const Node* node(uint64_t id) const { return id < nodes.size() && nodes[id].present ? &nodes[id] : nullptr; }
 };
@@ -209,6 +218,12 @@ template <class F> int guarded(F&& body) noexcept {
     catch (...) { return vdb_internal::set_error(VDB_ERR_DEVICE, "internal error: unknown C++ exception"); }
 }
 
+#define HN_TRY(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return vdb_internal::set_error(VDB_ERR_DEVICE, hipGetErrorString(e_));       \
+    } while (0)
+
 int zero_norm_error() {
     return vdb_internal::set_error(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
 }
@@ -236,6 +251,7 @@ int insert_node(Graph* g, uint64_t id, uint32_t row, long level_in, const float*
     nd = Node();
     nd.present = true; nd.level = (uint32_t)level; nd.row = row;
     nd.nbr.assign(level + 1, {});
+    nd.nbr_d.assign(level + 1, {});
     g->count++;
     if (!g->has_ep) { g->has_ep = true; g->ep = id; g->max_level = level; return VDB_OK; }
     uint64_t ep_id = g->ep;
@@ -262,43 +278,31 @@ int insert_node(Graph* g, uint64_t id, uint32_t row, long level_in, const float*
             if (!nearest.empty()) ep_id = nearest[0].id;
         }
     const size_t from = std::min(level, cur_max);
-    std::vector<uint32_t> pa, pb;
-    std::vector<float> pd;
+    std::vector<Nb> scored;
     for (size_t l = from;; --l) {
         const size_t m = l == 0 ? g->m_max0 : g->m;
         if ((rc = run_layer(g->ef_construction, l, nearest))) return rc;
         const size_t take = std::min(nearest.size(), m);          // select_neighbors_simple (graph.rs:202-204)
-        std::vector<uint64_t> sel(take);
-        for (size_t i = 0; i < take; ++i) sel[i] = nearest[i].id;
-        g->nodes[id].nbr[l] = sel;
-        // bidirectional links; the prunes of this layer touch disjoint lists, so their distances go out as one batch
-        std::vector<uint64_t> to_prune;
-        for (uint64_t nbid : sel) {
-            Node& nb = g->nodes[nbid];
-            if (nb.present && l < nb.nbr.size()) {
-                nb.nbr[l].push_back(id);
-                if (nb.nbr[l].size() > m) to_prune.push_back(nbid);
-            }
+        {
+            Node& me = g->nodes[id];
+            me.nbr[l].resize(take); me.nbr_d[l].resize(take);
+            for (size_t i = 0; i < take; ++i) { me.nbr[l][i] = nearest[i].id; me.nbr_d[l][i] = nearest[i].d; }
         }
-        if (!to_prune.empty()) {
-            pa.clear(); pb.clear();
-            for (uint64_t nbid : to_prune)
-                for (uint64_t x : g->nodes[nbid].nbr[l])
-                    if (g->node(x)) { pa.push_back(g->nodes[nbid].row); pb.push_back(g->nodes[x].row); }
-            pd.resize(pa.size());
-            if ((rc = vdb_internal::rows_eval(g->flat, pa.data(), pb.data(), pa.size(), pd.data()))) return rc;
-            g->stats[0] += pa.size(); g->stats[1]++;
-            size_t off = 0;
-            for (uint64_t nbid : to_prune) {                      // graph.rs:207-241 prune_neighbors
-                std::vector<Nb> scored;
-                for (uint64_t x : g->nodes[nbid].nbr[l])
-                    if (g->node(x)) { float dd = pd[off++]; scored.push_back(Nb{is_zero_norm_mark(dd) ? F32_MAX : dd, x}); }
-                std::stable_sort(scored.begin(), scored.end(), [](const Nb& a, const Nb& b) { return a.d < b.d; });
-                if (scored.size() > m) scored.resize(m);
-                std::vector<uint64_t>& lst = g->nodes[nbid].nbr[l];
-                lst.clear();
-                for (const Nb& s : scored) lst.push_back(s.id);
-            }
+        // bidirectional links (graph.rs:303-327); a list that grew beyond m is pruned at once (prune_neighbors, :207-241):
+        // its entries scored by their distance to the list's owner -- the cached edge distances --, stable sort, truncate
+        for (size_t i = 0; i < take; ++i) {
+            Node& nb = g->nodes[nearest[i].id];
+            if (!nb.present || l >= nb.nbr.size()) continue;
+            nb.nbr[l].push_back(id);
+            nb.nbr_d[l].push_back(nearest[i].d);                  // d(nb, new) == d(new, nb), bit for bit
+            if (nb.nbr[l].size() <= m) continue;
+            scored.clear();
+            for (size_t t = 0; t < nb.nbr[l].size(); ++t)
+                if (g->node(nb.nbr[l][t])) scored.push_back(Nb{is_zero_norm_mark(nb.nbr_d[l][t]) ? F32_MAX : nb.nbr_d[l][t], nb.nbr[l][t]});
+            std::stable_sort(scored.begin(), scored.end(), [](const Nb& a, const Nb& b) { return a.d < b.d; });
+            if (scored.size() > m) scored.resize(m);
+            nb.nbr[l].resize(scored.size()); nb.nbr_d[l].resize(scored.size());
+            for (size_t t = 0; t < scored.size(); ++t) { nb.nbr[l][t] = scored[t].id; nb.nbr_d[l][t] = scored[t].d; }
         }
         if (!nearest.empty()) ep_id = nearest[0].id;
         if (l == 0) break;
@@ -322,25 +326,65 @@ int add_rows(Graph* g, const uint64_t* ids, uint64_t first_id, const float* rows
     if ((rc = vdb_flat_add_bulk(g->flat, ids, first_id, rows, n, dim))) return rc;
     // When insert number i fails (zero-norm Cosine pair), the reference has stored node i without links and has not seen
     // the vectors after it (mod.rs:37-42 returns at the first error): the rows after i leave the row store again.
-    auto rollback_after = [&](size_t i_fail) {
+    auto rollback_after = [&](size_t i_fail) {                               // (size_t)-1: nothing was inserted
         for (size_t t = i_fail + 1; t < n; ++t) (void)vdb_flat_remove(g->flat, ids ? ids[t] : first_id + t);
     };
-    std::vector<float> scan;
-    constexpr size_t CHUNK = 256;
-    for (size_t c0 = 0; c0 < n; c0 += CHUNK) {
-        const size_t nc = std::min(CHUNK, n - c0);
-        if ((rc = vdb_internal::pairs_begin(g->flat, rows + c0 * dim, nc, dim))) return rc;   // also uploads the pending rows
+    if ((rc = vdb_flat_flush(g->flat))) { rollback_after((size_t)-1); return rc; }         // every row of the batch is on the device now
+    vdb_internal::DeviceView dv;
+    if ((rc = vdb_internal::device_view(g->flat, &dv))) { rollback_after((size_t)-1); return rc; }
+    std::vector<uint32_t> rowv(n);
+    for (size_t i = 0; i < n; ++i) {
+        rowv[i] = vdb_internal::row_of(g->flat, ids ? ids[i] : first_id + i);
+        if (rowv[i] == 0xffffffffu) { rollback_after((size_t)-1); return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "row was not stored (the same id twice in one batch?)"); }
+    }
+    // ---- distances ahead of the walks: chunk c's scan = the chunk's vectors (16 per launch) against device rows
+    // [0, last row of the chunk), written by the kernel into one of two mapped host matrices; chunk c+1's scan is enqueued
+    // before the host walks chunk c, so the passes over the rows and their transfer hide behind the sequential walks.
+    constexpr size_t CHUNK = 128;
+    const size_t need_ld = ((size_t)rowv[n - 1] + 1023) & ~(size_t)1023;
+    if (!g->scan_stream) {
+        HN_TRY(hipStreamCreateWithFlags(&g->scan_stream, hipStreamNonBlocking));
+        HN_TRY(hipEventCreateWithFlags(&g->scan_ev[0], hipEventDisableTiming));
+        HN_TRY(hipEventCreateWithFlags(&g->scan_ev[1], hipEventDisableTiming));
+    }
+    if (need_ld > g->scan_ld) {
+        const size_t ld_new = std::max(need_ld, g->scan_ld + g->scan_ld / 2);
+        for (int t = 0; t < 2; ++t) {
+            if (g->h_scan[t]) (void)hipHostFree(g->h_scan[t]);
+            g->h_scan[t] = nullptr;
+            HN_TRY(hipHostMalloc((void**)&g->h_scan[t], CHUNK * ld_new * sizeof(float), hipHostMallocMapped));
+            HN_TRY(hipHostGetDevicePointer((void**)&g->d_scan[t], g->h_scan[t], 0));
+        }
+        g->scan_ld = ld_new;
+    }
+    const size_t n_chunks = (n + CHUNK - 1) / CHUNK;
+    auto enqueue_scan = [&](size_t c) -> int {
+        const size_t c0 = c * CHUNK, nc = std::min(CHUNK, n - c0);
+        const uint32_t n_scan = rowv[c0 + nc - 1];                           // rows stored before the chunk's LAST vector
+        for (size_t q0 = 0; q0 < nc && n_scan; q0 += 16) {
+            vdb::ScanRowsParams sp{};
+            sp.rows = dv.rows; sp.ld = dv.ld; sp.dim = dv.dim; sp.nd = dv.nd; sp.metric = dv.metric; sp.mark = vdb_internal::ZERO_NORM_MARK;
+            sp.nq = (uint32_t)std::min<size_t>(16, nc - q0);
+            for (uint32_t j = 0; j < sp.nq; ++j) sp.qrow[j] = rowv[c0 + q0 + j];
+            sp.n_scan = n_scan; sp.out = g->d_scan[c & 1] + q0 * g->scan_ld; sp.ldm = g->scan_ld;
+            vdb::launch_scan_rows(sp, g->scan_stream);
+            g->stats[0] += (uint64_t)sp.nq * n_scan; g->stats[1]++;
+        }
+        HN_TRY(hipGetLastError());
+        HN_TRY(hipEventRecord(g->scan_ev[c & 1], g->scan_stream));
+        return VDB_OK;
+    };
+    auto drain = [&]() { (void)hipStreamSynchronize(g->scan_stream); };
+    if ((rc = enqueue_scan(0))) { drain(); rollback_after((size_t)-1); return rc; }
+    for (size_t c = 0; c < n_chunks; ++c) {
+        if (c + 1 < n_chunks && (rc = enqueue_scan(c + 1))) { drain(); rollback_after(c * CHUNK - 1); return rc; }
+        if (hipEventSynchronize(g->scan_ev[c & 1]) != hipSuccess) { drain(); rollback_after(c * CHUNK - 1); return vdb_internal::set_error(VDB_ERR_DEVICE, "scan failed"); }
+        const size_t c0 = c * CHUNK, nc = std::min(CHUNK, n - c0);
         for (size_t i = 0; i < nc; ++i) {
             const uint64_t id = ids ? ids[c0 + i] : first_id + c0 + i;
-            const uint32_t row = vdb_internal::row_of(g->flat, id);
-            if (row == 0xffffffffu) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "row was not stored");
             // every distance this insert can ask for: the new vector against the rows stored before it
-            scan.resize(std::max<size_t>(row, 1));
-            if (row) {
-                if ((rc = vdb_internal::query_vs_rows(g->flat, (uint32_t)i, row, scan.data()))) { rollback_after(c0 + i - 1); return rc; }
-                g->stats[1]++;
-            }
-            if ((rc = insert_node(g, id, row, levels ? levels[c0 + i] : level1, scan.data()))) { rollback_after(c0 + i); return rc; }
+            const float* scan = g->h_scan[c & 1] + i * g->scan_ld;
+            if ((rc = insert_node(g, id, rowv[c0 + i], levels ? levels[c0 + i] : level1, scan))) { drain(); rollback_after(c0 + i); return rc; }
         }
     }
     return VDB_OK;
@@ -372,6 +416,8 @@ int vdb_hnsw_create(int metric, size_t m, size_t ef_construction, size_t ef_sear
 void vdb_hnsw_destroy(vdb_hnsw_index* g) {
     if (!g) return;
     free_mirror(g);
+    if (g->scan_stream) { (void)hipStreamSynchronize(g->scan_stream); (void)hipStreamDestroy(g->scan_stream); }
+    for (int t = 0; t < 2; ++t) { if (g->h_scan[t]) (void)hipHostFree(g->h_scan[t]); if (g->scan_ev[t]) (void)hipEventDestroy(g->scan_ev[t]); }
     vdb_flat_destroy(g->flat);
     delete g;
 }
@@ -404,7 +450,11 @@ int vdb_hnsw_remove(vdb_hnsw_index* g, uint64_t id) {             // graph.rs:34
         for (uint64_t nid : gone.nbr[l]) {
             if (nid >= g->nodes.size() || !g->nodes[nid].present || l >= g->nodes[nid].nbr.size()) continue;
             auto& lst = g->nodes[nid].nbr[l];
-            lst.erase(std::remove(lst.begin(), lst.end(), id), lst.end());
+            auto& dst = g->nodes[nid].nbr_d[l];
+            size_t w = 0;
+            for (size_t t = 0; t < lst.size(); ++t)
+                if (lst[t] != id) { lst[w] = lst[t]; dst[w] = dst[t]; ++w; }
+            lst.resize(w); dst.resize(w);
         }
     g->count--;
     int rc = vdb_flat_remove(g->flat, id);
@@ -530,12 +580,6 @@ int search_host(vdb_hnsw_index* g, const float* queries, size_t nq, size_t dim, 
     if (zero.load()) return zero_norm_error();
     return VDB_OK;
 }
-
-#define HN_TRY(expr)                                                                                       \
-    do {                                                                                                   \
-        hipError_t e_ = (expr);                                                                            \
-        if (e_ != hipSuccess) return vdb_internal::set_error(VDB_ERR_DEVICE, hipGetErrorString(e_));       \
-    } while (0)
 
 void free_mirror(vdb_hnsw_index* g) {
     for (uint32_t** p : {&g->d_row_of, &g->d_level, &g->d_nbr0, &g->d_cnt0, &g->d_up_off, &g->d_nbrU, &g->d_cntU, &g->d_nbr0_row, &g->d_nbrU_row, &g->d_out_counts, &g->d_fail})
