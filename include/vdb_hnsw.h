@@ -14,6 +14,10 @@
  * the host with the candidate lists of ALL in-flight queries evaluated in one launch per traversal round.  Both give
  * the reference's results; there is no CPU distance path.
  *
+ * Inserts are sequential by definition and make no GPU round trip each: the distances are produced ahead of the walks
+ * (16 new vectors per pass over the stored rows, the next chunk scanned while the host walks the current one) and every
+ * edge keeps the distance it was created with, so a prune (graph.rs:207-241) recomputes nothing.
+ *
  * Not reproducible in the reference and fixed here: node levels come from StdRng::from_entropy() (graph.rs:101);
  * this index draws them from a seeded splitmix64 stream (`seed`), with the reference's formula (graph.rs:118-123).
  * Given the same seed and insertion order the graph and every search result are identical to the CPU restatement
