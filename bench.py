@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-f32-tier", action="store_true", help="skip the side measurement of the f32 MFMA tier")
     ap.add_argument("--no-gauss", action="store_true", help="skip the side measurement on unit-normalised Gaussian rows")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the two-batches-in-flight side measurement (keeps a profile's per-kernel averages synchronous)")
     ap.add_argument("--data", default="uniform", choices=["uniform", "gauss"], help="distribution of the HEADLINE index")
     ap.add_argument("--screen", type=int, default=1, help="1: bf16 screening tier first (default); 0: f32 MFMA tier only")
     ap.add_argument("--backend", default="nccl", help="nccl = RCCL behind the C ABI (default); gloo: the torch.distributed mirror of the call pattern, to rehearse several ranks on one GPU")
@@ -309,7 +310,7 @@ def main():
     # ---- two batches in flight (vdb_flat_search_batch_device_submit / _wait): what a server that keeps the GPU busy
     # sees.  Same K batches, every one complete inside the timed region; reported beside the synchronous headline.
     pipelined = None
-    if world == 1:
+    if world == 1 and not args.no_pipelined:
         bufs = [(torch.empty((B, k), dtype=torch.int64, device=device), torch.empty((B, k), dtype=torch.float32, device=device),
                  torch.empty((B,), dtype=torch.int32, device=device)) for _ in range(2)]
 

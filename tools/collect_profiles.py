@@ -6,6 +6,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def newest(pat):
     fs = glob.glob(os.path.join(root, pat)); fs.sort(key=os.path.getmtime); return fs[-1]
 shutil.copy(newest("gpurun_out/profS/*/*kernel_stats.csv"), os.path.join(root, f"profiles/{tag}_kernel_stats.csv"))
+cm = os.path.join(root, "gpurun_out/cert_margins.json")
+if os.path.exists(cm): shutil.copy(cm, os.path.join(root, f"profiles/{tag}_cert_margins.json"))
 out = {}
 for d in ("pmcA", "pmcB", "pmcF", "pmcW"):
     cc = newest(f"gpurun_out/{d}/*/*counter_collection.csv"); kt = cc.replace("counter_collection", "kernel_trace")
@@ -33,7 +35,8 @@ screened = "bf16" in (name or "")
 key = "hbm_bytes_per_launch_bf16_screen" if screened else "hbm_bytes_per_launch"
 tj[key] = 2 * fetch + write
 tj[key + "_detail"] = {"fetch_size_raw_bytes": fetch, "write_size_bytes": write, "kernel": name,
-    "source": f"profiles/{tag}_pmc_fused.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled per the gfx950 correction)"}
+    "tag": tag,
+    "source": f"profiles/{tag}_pmc_fused.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of bench.py --steps 3; FETCH doubled per the gfx950 correction)"}
 tj["workload"] = "bench.py default (1Mx768 f32, batch 256, k=10, 1 GPU)"
 json.dump(tj, open(tpath, "w"), indent=1)
 bench = open(os.path.join(root, "gpurun_out/bench_final.json")).read().strip().splitlines()[-1]

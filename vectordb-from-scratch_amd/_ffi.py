@@ -29,10 +29,35 @@ SYMBOLS = [
 _lib = None
 
 
+def _preload_torch_hip():
+    """PyTorch wheels ship their OWN libamdhip64.so / libhsa-runtime64.so (torch/lib, found by RPATH) and ask for them by
+    file name, while this library asks for the SONAME libamdhip64.so.7.  If this library is loaded first it pulls in the
+    ROCm installation's runtime, a later `import torch` then brings a second HIP + HSA runtime into the process, and the
+    second one finds no GPU ("No HIP GPUs are available").  Loading torch's copy first -- without importing torch -- makes
+    both resolve to that one runtime, whatever the import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is not None:
         return _lib
+    _preload_torch_hip()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build the HIP extension first (python vectordb-from-scratch_amd/build.py "

@@ -667,27 +667,36 @@ void launch_select(const SelectParams& p, uint32_t nq, hipStream_t s) {
 //     along the way (each loses less than 2^-149; the MFMA accumulators themselves keep denormals -- measured).
 constexpr double CERT_TINY_NORM = 9.094947017729282e-13;        // 2^-40
 __device__ __forceinline__ double cert_floor(const RerankParams& p) { return (double)p.ld * 7.174648137343064e-43; }   // ld 2^-140
-__device__ __forceinline__ bool cert_test(const RerankParams& p, uint32_t q, float T, double ek, double qn) {
+// The test has the form   lhs(e_k) < a + b * (T - |T| tslack)   with lhs = e_k, or e_k^2 (1 + eps) under Euclid.  a, b and
+// tslack depend on the QUERY only (norms, rounding-error norm, per-index scalars): they are computed once per workgroup --
+// double-precision square roots and divisions -- and every candidate thread then evaluates the test in three flops.
+struct CertConsts { double a, b, tslack, lhs_scale; int square; int ok; };
+__device__ __forceinline__ CertConsts cert_consts(const RerankParams& p, uint32_t q, double qn) {
+    CertConsts c{0.0, 1.0, 0.0, 1.0, 0, 1};
     const double eps = (double)p.eps_coef;
     const double ndmax = sqrt((double)__uint_as_float(p.nd2max_bits[0]));
     const double fl = cert_floor(p);
-    if (!(qn >= CERT_TINY_NORM)) return false;
+    if (!(qn >= CERT_TINY_NORM)) { c.ok = 0; return c; }
     if (p.metric == COSINE) {
         const uint32_t mb = p.nd2max_bits[5];
-        if (mb && !(__uint_as_float(~mb) >= (float)(CERT_TINY_NORM * CERT_TINY_NORM))) return false;
+        if (mb && !(__uint_as_float(~mb) >= (float)(CERT_TINY_NORM * CERT_TINY_NORM))) { c.ok = 0; return c; }
     }
+    if (p.metric == EUCLID) { c.square = 1; c.lhs_scale = 1.0 + eps; }
     if (p.qerr && p.lb_scores) {
         // bf16 screening tier, Dot / Euclid: T is a LOWER-BOUND score (FusedBf16Params::margin) -- the bf16 rounding of
         // row and query, the MFMA accumulation and the row's share of the f32-fold budget were subtracted per row in the
         // kernel, so only the query's own terms are left here and no per-index maximum enters: one huge-norm row
-        // loosens nobody's certificate but its own.  (1 - 2^-22): the f32 rounding of the margin fma.
-        const double Tl = (double)T - fabs((double)T) * 2.4e-7;
-        if (p.metric == DOT) return ek < Tl - fl;
-        return ek * ek < Tl + qn * qn - eps * (qn * qn + ek * ek) - 4.0 * fl;
+        // loosens nobody's certificate but its own.  tslack: the f32 rounding of the margin fma.
+        //   Dot:     e_k < Tl - fl                                   Euclid:  e_k^2 (1 + eps) < Tl + |q|^2 (1 - eps) - 4 fl
+        c.tslack = 2.4e-7;
+        c.a = p.metric == DOT ? -fl : qn * qn * (1.0 - eps) - 4.0 * fl;
+        return c;
     }
+    double E = 0.0, Ec = 0.0;
     if (p.qerr) {
         // bf16 screening tier (Cosine: the relative rounding error of a row is bounded by 2^-9 whatever its norm, so the
-        // per-index maximum of it is a local quantity already).  With e_q = q - bf16(q) (known) and e_d = d - bf16(d):
+        // per-index maximum of it is a local quantity already; Dot / Euclid land here only for the raw-score diagnostics).
+        // With e_q = q - bf16(q) (known) and e_d = d - bf16(d):
         //   dot(q,d) - dot(bf16 q, bf16 d) = e_q.d + bf16(q).e_d ,  |.| <= |e_q||d| + |bf16 q||e_d|   (Cauchy-Schwarz)
         // plus the f32 accumulation inside the MFMAs (c_acc |q||d|).  |bf16 q| <= 1.004 |q|; 1 % covers the f32
         // evaluation of the norms.  eps is the f32 tier's coefficient (oracle fold + fma chain).
@@ -695,22 +704,25 @@ __device__ __forceinline__ bool cert_test(const RerankParams& p, uint32_t q, flo
         const double emax = sqrt((double)__uint_as_float(p.nd2max_bits[2]));
         const double rmax = sqrt((double)__uint_as_float(p.nd2max_bits[3]));
         const double cacc = (double)p.c_acc;
-        if (p.metric == DOT) {
-            const double E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
-            return ek < (double)T - E - eps * qn * ndmax - fl;
-        } else if (p.metric == COSINE) {
-            const double Ec = 1.01 * (eq / qn + 1.004 * rmax) + cacc;
-            return ek < 1.0 + (double)T / qn - Ec - eps - fl / (qn * CERT_TINY_NORM);
-        } else {
-            const double E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
-            const double s = qn + ndmax;
-            return ek * ek < (double)T + qn * qn - 2.0 * E - eps * (s * s + ek * ek) - 4.0 * fl;
-        }
+        E = 1.01 * (eq * ndmax + 1.004 * qn * emax) + cacc * qn * ndmax;
+        Ec = 1.01 * (eq / qn + 1.004 * rmax) + cacc;
     }
-    if (p.metric == DOT) return ek < (double)T - eps * qn * ndmax - fl;
-    if (p.metric == COSINE) return ek < 1.0 + (double)T / qn - eps - fl / (qn * CERT_TINY_NORM);
-    const double s = qn + ndmax;
-    return ek * ek < (double)T + qn * qn - eps * (s * s + ek * ek) - 4.0 * fl;
+    //   Dot:     e_k < T - E - eps |q| max|d| - fl
+    //   Cosine:  e_k < 1 + T / |q| - Ec - eps - fl / (|q| 2^-40)
+    //   Euclid:  e_k^2 (1 + eps) < T + |q|^2 - 2 E - eps (|q| + max|d|)^2 - 4 fl
+    if (p.metric == DOT) c.a = -E - eps * qn * ndmax - fl;
+    else if (p.metric == COSINE) { c.a = 1.0 - Ec - eps - fl / (qn * CERT_TINY_NORM); c.b = 1.0 / qn; }
+    else { const double s = qn + ndmax; c.a = qn * qn - 2.0 * E - eps * s * s - 4.0 * fl; }
+    return c;
+}
+__device__ __forceinline__ bool cert_eval(const CertConsts& c, float T, double ek) {
+    if (!c.ok) return false;
+    const double Tl = (double)T - fabs((double)T) * c.tslack;
+    const double lhs = c.square ? ek * ek * c.lhs_scale : ek;
+    return lhs < c.a + c.b * Tl;
+}
+__device__ __forceinline__ bool cert_test(const RerankParams& p, uint32_t q, float T, double ek, double qn) {
+    return cert_eval(cert_consts(p, q, qn), T, ek);
 }
 
 // The inverse of cert_test: the smallest score T* such that cert_test(T) holds for every T > T*.  Every row whose
@@ -790,10 +802,12 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
     __shared__ uint64_t sId[RR_MAX];
     __shared__ uint32_t sRowIdx[RR_MAX];
     __shared__ uint32_t sAnyNan, sNanKey, sNext, sRealW[RR_THREADS / 64];
+    __shared__ CertConsts sCert;
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t cnt = p.cand_cnt[q] < p.kp ? p.cand_cnt[q] : p.kp;
     const uint64_t* cand = p.cand + (size_t)q * p.cand_stride;
     if (tid == 0) { sAnyNan = 0; sNanKey = 0; sNext = 0; }
+    if (tid == RR_THREADS - 1) sCert = cert_consts(p, q, (double)p.qnorm[q]);     // once per query, beside the row staging (published by the barriers below)
     if (tid < RR_MAX) {
         uint32_t row = 0xffffffffu;
         if (tid < cnt) {
@@ -899,7 +913,6 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
         const bool clean = !sNanKey && real == processed;          // no NaN score, no ineligible candidate so far
         const bool can_test = clean && nout == p.k && nout > 0;
         const double ek = can_test ? (double)ordered_to_f32(sDist[nout - 1]) : 0.0;
-        const double qn = (double)qn_f;
         cut_ok = can_test; cut_ek = ek;
         if (processed < cnt) {
             // every candidate not yet re-ranked tests "would the result be certified if the re-rank stopped just
@@ -908,7 +921,7 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
             __syncthreads();
             if (can_test && tid >= processed && tid < cnt) {
                 const float T = ordered_to_f32((uint32_t)(cand[tid] >> 32));
-                if (cert_test(p, q, T, ek, qn)) atomicMin(&sNext, tid);
+                if (cert_eval(sCert, T, ek)) atomicMin(&sNext, tid);
             }
             __syncthreads();
             const uint32_t m = sNext;
@@ -930,7 +943,7 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
                 T = p.thr[q]; have_T = true;
             }
             cert = 1;
-            if (have_T && !(can_test && cert_test(p, q, T, ek, qn))) cert = 0;
+            if (have_T && !(can_test && cert_eval(sCert, T, ek))) cert = 0;
         }
         break;
     }
