@@ -241,6 +241,8 @@ int vdb_flat_set_tiers(vdb_flat_index *h, unsigned flags);
  *   out_scores [nq][rows uploaded] f32 (the NaN pattern 0xffffffff = no key: tombstoned row); nq <= 256;
  *   raw = 0: the scores the tier ranks by (Dot / Euclid: lower-bound scores, score - g_q * margin_row);
  *   raw = 1: the plain scores fma(acc, alpha, beta) (under Dot: -acc, the raw MFMA accumulator);
+ *   raw = 2: the f32 MFMA TIER's scores (v_mfma_f32_32x32x2_f32; dense_scores_kernel over every row, bit-identical to the
+ *            fused f32 kernel's); a following cert_probe then evaluates the f32 tier's certificate (eps_coef only);
  *   out_qinfo [nq][4]: exact-order |q|, the bound on |q - bf16(q)|, g_q, 0;
  *   out_consts [8]: eps_coef, c_acc, kappa, max |d|, max |d - bf16(d)|, max |d - bf16(d)|/|d|, 1 if lower-bound scores, ld.
  * vdb_flat_debug_rows: number of device rows.  vdb_flat_debug_row_info: out [rows][4] = exact-order |d|, alpha, beta, margin (0 under Cosine).

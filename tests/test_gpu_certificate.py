@@ -178,6 +178,45 @@ def test_score_error_stays_inside_the_certified_bound(vdb, metric, kind):
     assert worst["C_ratio"] <= 1.0, worst
 
 
+@pytest.mark.parametrize("kind", ["cancel", "scales", "bf16ties"])
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_f32_tier_score_error_stays_inside_its_bound(vdb, metric, kind):
+    """The same for the f32-input-MFMA tier (`eps_coef` "is similarly asserted"): its scores
+    (v_mfma_f32_32x32x2_f32 fma chain, raw = 2) against the oracle's distances, budget = eps_coef terms only."""
+    rng = np.random.default_rng(zlib.crc32(f"f32/{metric}/{kind}".encode()))
+    rows, q = make_case(kind, metric, rng)
+    rows, q = np.ascontiguousarray(rows[:20_000]), np.ascontiguousarray(q[:16])
+    n = rows.shape[0]
+    ix = vdb.GpuFlatIndex(vdb.DistanceMetric(metric), keep_host_copy=False)
+    ix.add_bulk(rows)
+    s32, qinfo, c = ix.debug_screen_scores(q, raw=2)
+    info = ix.debug_row_info().astype(np.float64)
+    nd = info[:, 0]
+    eps, ld, ndmax = c["eps_coef"], c["ld"], c["nd_max"]
+    assert not np.isnan(s32).any()
+    TINY, floor = 2.0 ** -40, ld * 2.0 ** -140
+    nd_pos_min = float(nd[nd > 0].min())
+    worst = 0.0
+    for b in range(q.shape[0]):
+        dist = exact_distances(metric, rows, q[b])
+        qn = float(qinfo[b, 0])
+        fl = ix.debug_cert_probe(np.full(n, b, np.uint32), s32[b], dist)
+        assert fl.sum() == 0, (metric, kind, b, np.nonzero(fl)[0][:5])
+        if qn < TINY or (metric == 1 and nd_pos_min < TINY):
+            continue
+        s, d64 = s32[b].astype(np.float64), dist.astype(np.float64)
+        if metric == 2:
+            err, budget = np.abs(s - d64), eps * qn * ndmax + floor
+        elif metric == 0:      # (beta carries -eps |d|^2 since round 2: the safe direction, added to the two-sided budget)
+            err, budget = np.abs(s + qn * qn - d64 * d64), eps * ((qn + ndmax) ** 2 + d64 * d64) + eps * nd * nd + 4 * floor
+        else:
+            err, budget = np.abs(1.0 + s / qn - d64), eps + floor / (qn * TINY)
+        worst = max(worst, float(np.max(err / budget)))
+    MARGINS[f"f32_tier/{['euclid', 'cosine', 'dot'][metric]}/{kind}"] = {"B_ratio": worst, "rows": n, "dim": rows.shape[1], "eps_coef": eps}
+    print(f"\n[certificate] f32 tier metric={metric} {kind}: worst error/budget = {worst:.4f}")
+    assert worst <= 1.0
+
+
 def test_adversarial_data_still_gives_the_oracle_top_k(vdb):
     """The same adversarial sets through the ordinary search: certified answers equal the oracle's, whichever tier gave them."""
     for metric in (0, 1, 2):

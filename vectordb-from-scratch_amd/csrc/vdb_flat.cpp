@@ -109,7 +109,7 @@ constexpr uint32_t MAX_SELECT = 2048;   // select kernel capacity (kk)
 
 struct Workspace {
     DevBuf<float> w_qp, w_qnorm, w_thr, w_qin, w_outd, w_qerr, w_qg, w_dbg;
-    uint32_t dbg_nq = 0; bool dbg_lb = false;             // vdb_flat_debug_screen_scores left this many prepared queries in the workspace
+    uint32_t dbg_nq = 0; bool dbg_lb = false, dbg_f32 = false;             // vdb_flat_debug_screen_scores left this many prepared queries in the workspace
     DevBuf<uint64_t> w_dense, w_samp, w_pool, w_cand, w_exact, w_exsel, w_mask_ids, w_outi;
     DevBuf<uint32_t> w_cnt, w_rowmask, w_flags, w_outc, w_subcnt, w_depth;
     DevBuf<uint16_t> w_qb;                                  // bf16 copy of the padded queries (screening tier)
@@ -1757,7 +1757,43 @@ int vdb_flat_debug_screen_scores(vdb_flat_index* ix, const float* queries, size_
     ix->cur->status_dirty = true;
     HIP_TRY(hipMemsetAsync(ix->cur->w_flags.p, 0, 16, s));
     HIP_TRY(hipMemcpyAsync(ix->cur->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
-    const bool lb = ix->d_margin && !raw;
+    const bool lb = ix->d_margin && raw == 0;
+    if (raw == 2) {
+        // the f32 MFMA tier's scores: dense_scores_kernel over EVERY row -- the production kernel of indexes up to 16384 rows,
+        // and bit-identical to the fused f32 kernel's scores by construction (same K order, same score expression)
+        if ((size_t)nq * n > ((size_t)1 << 28)) return fail(VDB_ERR_INVALID_ARGUMENT, "index too large for the f32-tier score dump");
+        if ((rc = ix->cur->w_dense.ensure((size_t)SUPER * n))) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->cur->w_qin.p, queries, nq * dim * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemsetAsync(ix->cur->w_flags.p, 0, 16, s));
+        vdb::QueryPrepParams qp2{ix->cur->w_qin.p, (uint32_t)dim, (uint32_t)nq, ix->cur->w_qp.p, ld, SUPER, ix->cur->w_qnorm.p, ix->cur->w_thr.p, vdb::EUCLID,
+                                 ix->cur->w_flags.p, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr};
+        vdb::launch_query_prep(qp2, s);
+        vdb::DenseParams dp{ix->d_rows, ld, n, ix->cur->w_qp.p, round_up((uint32_t)nq, 32), ix->d_alpha, ix->d_beta, ix->d_live, n, ix->cur->w_dense.p, n};
+        vdb::launch_dense_scores(dp, s);
+        HIP_TRY(hipGetLastError());
+        std::vector<uint64_t> keys((size_t)nq * n);
+        std::vector<float> qn2(nq);
+        uint32_t sc2[8] = {0};
+        HIP_TRY(hipMemcpyAsync(keys.data(), ix->cur->w_dense.p, keys.size() * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(qn2.data(), ix->cur->w_qnorm.p, nq * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(sc2, ix->d_scalars, 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (size_t i = 0; i < keys.size(); ++i) {
+            uint32_t bits = 0xffffffffu;                                    // no key (tombstoned row)
+            if (keys[i] != vdb::EMPTY_KEY) { const float f = vdb::ordered_to_f32((uint32_t)(keys[i] >> 32)); memcpy(&bits, &f, 4); }
+            memcpy(out_scores + i, &bits, 4);
+        }
+        if (out_qinfo)
+            for (size_t q = 0; q < nq; ++q) { out_qinfo[4 * q] = qn2[q]; out_qinfo[4 * q + 1] = 0.0f; out_qinfo[4 * q + 2] = 0.0f; out_qinfo[4 * q + 3] = 0.0f; }
+        if (out_consts) {
+            auto f = [](uint32_t b) { float v; memcpy(&v, &b, 4); return (double)v; };
+            out_consts[0] = eps_coef(ix); out_consts[1] = 0.0; out_consts[2] = 0.0; out_consts[3] = std::sqrt(f(sc2[0]));
+            out_consts[4] = 0.0; out_consts[5] = 0.0; out_consts[6] = 0.0; out_consts[7] = (double)ld;
+        }
+        ix->cur->dbg_nq = (uint32_t)nq; ix->cur->dbg_lb = false; ix->cur->dbg_f32 = true;
+        return VDB_OK;
+    }
+    ix->cur->dbg_f32 = false;
     vdb::QueryPrepParams qp{ix->cur->w_qin.p, (uint32_t)dim, (uint32_t)nq, ix->cur->w_qp.p, ld, SUPER, ix->cur->w_qnorm.p, ix->cur->w_thr.p, vdb::EUCLID,
                             ix->cur->w_flags.p, ix->cur->w_qb.p, ix->cur->w_qerr.p, ix->d_margin ? ix->cur->w_qg.p : nullptr, margin_plan(ix).kappa,
                             nullptr, nullptr};
@@ -1839,7 +1875,7 @@ int vdb_flat_debug_cert_probe(vdb_flat_index* ix, const uint32_t* qi, const floa
     // the same parameter block the screening tier's re-rank gets (pass_bf16)
     vdb::RerankParams rp{};
     rp.metric = ix->metric; rp.eps_coef = eps_coef(ix); rp.nd2max_bits = ix->d_scalars; rp.qnorm = ix->cur->w_qnorm.p; rp.ld = ix->ld;
-    rp.qerr = ix->cur->w_qerr.p; rp.c_acc = c_acc_bf16(ix); rp.lb_scores = ix->cur->dbg_lb ? 1u : 0u;
+    rp.qerr = ix->cur->dbg_f32 ? nullptr : ix->cur->w_qerr.p; rp.c_acc = c_acc_bf16(ix); rp.lb_scores = ix->cur->dbg_lb ? 1u : 0u;   // dbg_f32: the f32 tier's parameter block (pass_f32)
     vdb::launch_cert_probe(rp, d_qi.p, d_T.p, d_ek.p, (uint32_t)n, d_out.p, s);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d_out.p, n * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)

@@ -296,14 +296,15 @@ class GpuFlatIndex(Index):
 
     # ---- certificate diagnostics (include/vdb_flat.h "Diagnostics of the screening tier's CERTIFICATE")
     def debug_screen_scores(self, queries, raw=False):
-        """(scores [nq, rows] f32, qinfo [nq, 4], consts dict) from the production filter kernel with open thresholds."""
+        """(scores [nq, rows] f32, qinfo [nq, 4], consts dict) from the production filter kernel with open thresholds.
+        raw: 0 the scores the screening tier ranks by, 1 its plain scores, 2 the f32 MFMA tier's scores."""
         qs = np.ascontiguousarray(queries, dtype=np.float32)
         nq, dim = qs.shape
         n = int(self._L.vdb_flat_debug_rows(self._h))
         scores = np.empty((nq, n), dtype=np.float32)
         qinfo = np.zeros((nq, 4), dtype=np.float32)
         consts = np.zeros(8, dtype=np.float64)
-        rc = self._L.vdb_flat_debug_screen_scores(self._h, _fp(qs), nq, dim, int(bool(raw)), _fp(scores), _fp(qinfo),
+        rc = self._L.vdb_flat_debug_screen_scores(self._h, _fp(qs), nq, dim, int(raw), _fp(scores), _fp(qinfo),
                                                   consts.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
         if rc:
             _raise(rc)
