@@ -195,8 +195,21 @@ def main():
     # ---- the search path: N = 1 the plain device call; N > 1 the C-ABI shard group (RCCL) or, for rehearsals, its mirror
     mptr = mask_t.data_ptr() if mask_t is not None else 0
     group, rccl_ranks = None, None
+    shard_note = None
     if world > 1 and args.backend == "nccl":
-        group = ShardGroup.from_torch_distributed(local_rank)
+        # every rank must take the same path: agree on whether the C-ABI group came up everywhere
+        try:
+            group = ShardGroup.from_torch_distributed(local_rank)
+            ok, why = 1, ""
+        except Exception as e:                                   # noqa: BLE001 -- reported in the line, never swallowed
+            group, ok, why = None, 0, f"{type(e).__name__}: {e}"
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            group = None
+            shard_note = ("C-ABI shard group could not be created on every rank (" + (why or "another rank failed") +
+                          "); this run used the torch.distributed mirror of the same call pattern")
+    if group is not None:
         rccl_ranks = group.world()
         search = group_search(group, index, mask_ptr=mptr, mask_bits=mask_bits)
     else:
@@ -436,6 +449,7 @@ def main():
                        "n_rows": n_rows, "rows_per_gpu": local_rows, "dim": dim, "batch": B, "k": k, "distance": mname,
                        "sharding": f"rows/{world}, exchange = RCCL all-gather + merge behind the C ABI (vdb_flat_search_batch_sharded)"
                                    if group is not None else (f"rows/{world} ({args.backend} mirror of the call pattern)" if world > 1 else "single GPU"),
+                       "sharding_note": shard_note,
                        "inputs": "queries and outputs resident in HBM",
                        "arithmetic": ("rows, queries and every reported distance are f32 (exact re-rank in the reference's operation "
                                       "order, bit-identical to the f32 oracle); candidates are RANKED by bf16-MFMA scores under an error "
