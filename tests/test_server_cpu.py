@@ -1,0 +1,90 @@
+"""The batch endpoint and the metrics of the reference's server (src/server/routes.rs:330-385, :417-431; src/metrics.rs),
+mirrored in vectordb-from-scratch_amd/server.py.  CPU part: the MetricsCollector known answers (metrics.rs:84-114) and the
+JSON plumbing over an index with no device behind it; the reference's own endpoint tests (routes.rs:637-721) are replayed on
+the GPU in tests/test_gpu_server.py."""
+import numpy as np
+import pytest
+
+from conftest import load_package
+
+
+def test_metrics_collector_known_answers():
+    vdb = load_package()
+    from vectordb_from_scratch_amd.server import MetricsCollector
+    m = MetricsCollector()                                   # metrics.rs:84-93
+    m.record_insert(); m.record_insert(); m.record_delete()
+    assert (m.total_inserts(), m.total_deletes(), m.total_queries()) == (2, 1, 0)
+    m = MetricsCollector()                                   # metrics.rs:96-106
+    for us in (100, 200, 300):
+        m.record_query(us * 1e-6)
+    assert m.total_queries() == 3 and abs(m.avg_query_latency_us() - 200.0) < 1.0
+    assert abs(m.percentile_query_latency_us(50.0) - 200.0) < 1.0
+    m = MetricsCollector()                                   # metrics.rs:109-113
+    assert m.avg_query_latency_us() == 0.0 and m.percentile_query_latency_us(99.0) == 0.0
+    # percentile index = round(p/100 * (n-1)) on the sorted list (metrics.rs:68-70)
+    m = MetricsCollector()
+    for us in (50, 10, 40, 30, 20):
+        m.record_query(us * 1e-6)
+    assert [m.percentile_query_latency_us(p) for p in (0, 50, 95, 99, 100)] == [10.0, 30.0, 50.0, 50.0, 50.0]
+
+
+def test_filter_from_json_is_the_serde_shape():
+    load_package()
+    from vectordb_from_scratch_amd.server import filter_from_json
+    from vectordb_from_scratch_amd import Metadata
+    f = filter_from_json({"op": "and", "filters": [{"op": "eq", "field": "color", "value": "red"},
+                                                    {"op": "or", "filters": [{"op": "exists", "field": "size"}, {"op": "ne", "field": "shape", "value": "round"}]}]})
+    assert f.matches(Metadata({"color": "red", "size": "l", "shape": "round"}))
+    assert f.matches(Metadata({"color": "red"}))            # ne on a missing field matches (storage.rs:65)
+    assert not f.matches(Metadata({"color": "blue", "size": "l"}))
+    with pytest.raises(ValueError):
+        filter_from_json({"op": "between"})
+
+
+def test_batch_endpoint_plumbing_over_a_fake_index():
+    """Routing, per-query default k, error mapping and the one-latency-sample-per-batch rule, with an Index that needs no GPU
+    (brute force in numpy -- test double only)."""
+    vdb = load_package()
+    from starlette.testclient import TestClient
+    from vectordb_from_scratch_amd.server import AppState, create_app
+
+    class NumpyIndex(vdb.Index):
+        def __init__(self):
+            self.rows = {}
+
+        def add(self, id, vector):
+            self.rows[id] = vector
+
+        def remove(self, id):
+            self.rows.pop(id, None)
+
+        def search(self, query, k):
+            d = sorted((float(np.linalg.norm(v.data - query.data)), i) for i, v in self.rows.items())
+            return [(i, np.float32(x)) for x, i in d[:k]]
+
+        def get_vector(self, id):
+            return self.rows.get(id)
+
+        def metric(self):
+            return vdb.DistanceMetric.Euclidean
+
+        def len(self):
+            return len(self.rows)
+
+    state = AppState(vdb.VectorStore.with_index(NumpyIndex()))
+    client = TestClient(create_app(state))
+    r = client.post("/vectors/batch", json={"vectors": [{"id": f"v{i}", "vector": [float(i), 0.0], "metadata": {"parity": "even" if i % 2 == 0 else "odd"}} for i in range(30)]})
+    assert r.status_code == 201 and r.json() == {"inserted": 30}
+    assert client.get("/health").json() == {"status": "ok", "vector_count": 30}
+    r = client.post("/search/batch", json={"queries": [{"vector": [3.2, 0.0], "k": 2}, {"vector": [10.0, 0.0]}]})
+    assert r.status_code == 200
+    body = r.json()
+    assert [x["id"] for x in body[0]] == ["v3", "v4"] and len(body[1]) == 10       # k defaults to 10 (routes.rs:337)
+    r = client.post("/search/batch", json={"queries": [{"vector": [3.2, 0.0], "k": 3}], "filter": {"op": "eq", "field": "parity", "value": "even"}})
+    assert [x["id"] for x in r.json()[0]] == ["v4", "v2", "v6"]                   # 3k over-fetch, post-filter, take k (storage.rs:268-287)
+    r = client.post("/search/batch", json={"queries": [{"vector": [1.0, 2.0, 3.0], "k": 1}]})
+    assert r.status_code == 400 and "Dimension mismatch" in r.json()["error"]     # routes.rs:357-364
+    m = client.get("/metrics").json()
+    assert m["total_inserts"] == 30 and m["total_queries"] == 2                   # ONE sample per successful batch (routes.rs:365-369)
+    assert m["p50_query_latency_us"] >= 0 and set(m) == {"total_queries", "total_inserts", "total_deletes", "avg_query_latency_us",
+                                                          "p50_query_latency_us", "p95_query_latency_us", "p99_query_latency_us"}
