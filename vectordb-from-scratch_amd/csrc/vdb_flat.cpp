@@ -199,6 +199,7 @@ struct vdb_flat_index {
     uint32_t* h_pairs = nullptr; float* h_pout = nullptr; size_t h_pairs_cap = 0, h_pout_cap = 0;
     uint32_t pairs_nq = 0;
     bool begin_locked = false;
+    hipEvent_t ev_pass[2] = {nullptr, nullptr};             // fork / join of the alternating passes of a large batch (pass_bf16)
     hipEvent_t ev_order = nullptr;                          // orders the handle's stream before the null stream (search_batch_device_begin)
     int screen = 1;                                         // 1: bf16 screening tier first (default), 0: f32 MFMA tier only
     uint64_t stats[16] = {0};                               // counters of the last COMPLETED search (copied from its context)
@@ -641,7 +642,7 @@ int pass_f32(Index* ix, hipStream_t s, const float* qp, const float* qnorm, floa
 // keys -> exact re-rank, certified with the bf16 error bound.  Queries come from ix->cur->w_qp / w_qb / w_qnorm.
 int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& pl, const uint32_t* d_rowmask,
               uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, uint32_t* d_cert, uint32_t* d_ovf,
-              uint32_t* d_status, float* d_thr_next) {
+              uint32_t* d_status, float* d_thr_next, bool allow_alt = false) {
     int rc;
     const uint32_t n = ix->n_uploaded, ld = ix->ld;
     const uint32_t S = pl.S, kp = pl.kp, KT = pl.kt;
@@ -653,30 +654,55 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
     const uint32_t capl = 256;
     const uint32_t n_wg = std::min<uint32_t>((uint32_t)ix->n_cu, (n + vdb::fused_bf16_tile_rows() - 1) / vdb::fused_bf16_tile_rows());
     const uint32_t n_sub = vdb::fused_bf16_subpools_per_query(n_wg);
-    if ((rc = ix->cur->w_dense.ensure((size_t)SUPER * M))) return rc;
-    if ((rc = ix->cur->w_cand.ensure((size_t)SUPER * kp))) return rc;
-    if ((rc = ix->cur->w_samp.ensure((size_t)SUPER * std::max(kp, KT)))) return rc;
-    if ((rc = ix->cur->w_pool.ensure((size_t)SUPER * n_sub * capl))) return rc;
-    if ((rc = ix->cur->w_subcnt.ensure((size_t)SUPER * n_sub))) return rc;
-    uint32_t* d_cnt_a = ix->cur->w_cnt.p;
-    uint32_t* d_cand_cnt = ix->cur->w_cnt.p + 2 * SUPER;
+    // A batch above 256 queries takes several passes (BASELINE config 3: four).  They are independent, so they ALTERNATE between
+    // this context and the handle's other workspace and stream when that one is idle: the latency-bound tail of pass i (its
+    // slowest re-rank workgroups, a few CUs) then runs beside the head of pass i+1 instead of in front of it.  The per-query
+    // arrays (queries, thresholds, flags, outputs) are indexed by q0 and shared; only the pass-local buffers are doubled.
+    Workspace* alt = nullptr;
+    if (allow_alt && nq > SUPER && !ix->profile && !ix->kn.rr_depth) {
+        Workspace* o = (ix->cur == &ix->wsv[0]) ? &ix->wsv[1] : &ix->wsv[0];
+        if (!o->busy) alt = o;
+    }
+    Workspace* const Wv[2] = {ix->cur, alt ? alt : ix->cur};
+    const hipStream_t Sv[2] = {s, alt ? alt->stream : s};
+    for (int t = 0; t < (alt ? 2 : 1); ++t) {
+        Workspace* w = Wv[t];
+        if ((rc = w->w_dense.ensure((size_t)SUPER * M))) return rc;
+        if ((rc = w->w_cand.ensure((size_t)SUPER * kp))) return rc;
+        if ((rc = w->w_samp.ensure((size_t)SUPER * std::max(kp, KT)))) return rc;
+        if ((rc = w->w_pool.ensure((size_t)SUPER * n_sub * capl))) return rc;
+        if ((rc = w->w_subcnt.ensure((size_t)SUPER * n_sub))) return rc;
+        if ((rc = w->w_cnt.ensure(4 * SUPER + 16))) return rc;
+    }
+    if (alt) {                                                   // the other stream starts behind query_prep and the row mask
+        if (!ix->ev_pass[0]) {
+            HIP_TRY(hipEventCreateWithFlags(&ix->ev_pass[0], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ix->ev_pass[1], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(ix->ev_pass[0], s));
+        HIP_TRY(hipStreamWaitEvent(Sv[1], ix->ev_pass[0], 0));
+    }
     ix->cur->stats[4] = S;
     const float eps = eps_coef(ix);
-    for (uint32_t q0 = 0; q0 < nq; q0 += SUPER) {
+    for (uint32_t q0 = 0, pass = 0; q0 < nq; q0 += SUPER, ++pass) {
         const uint32_t nb = std::min(SUPER, nq - q0);
+        Workspace* const W = Wv[pass & 1];                        // pass-local buffers
+        const hipStream_t s = Sv[pass & 1];                       // (shadows the caller's stream inside the loop)
+        uint32_t* d_cnt_a = W->w_cnt.p;
+        uint32_t* d_cand_cnt = W->w_cnt.p + 2 * SUPER;
         vdb::FusedBf16Params fp{};
         fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->cur->w_qb.p + (size_t)q0 * ld;
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
         fp.margin = ix->d_margin; fp.qg = ix->d_margin ? ix->cur->w_qg.p + q0 : nullptr;
-        fp.thr = ix->cur->w_thr.p + q0; fp.pool = ix->cur->w_pool.p; fp.pool_cnt = ix->cur->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
+        fp.thr = ix->cur->w_thr.p + q0; fp.pool = W->w_pool.p; fp.pool_cnt = W->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
         fp.ablate = ix->kn.bf16_ablate;
         fp.n_sample = S; fp.sample_shift = pl.shift;
-        fp.sample_block = ix->kn.sample_block ? (n / (S / 256u)) : 0u; fp.minkeys = ix->cur->w_dense.p; fp.minkey_stride = M;
+        fp.sample_block = ix->kn.sample_block ? (n / (S / 256u)) : 0u; fp.minkeys = W->w_dense.p; fp.minkey_stride = M;
         vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);    // (the sample always reads the f32 rows)
 
         vdb::SelectParams sp{};
-        sp.keys = ix->cur->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = KT;
-        sp.out_stride = KT; sp.out_keys = ix->cur->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->cur->w_thr.p + q0; sp.ovf = nullptr;
+        sp.keys = W->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = KT;
+        sp.out_stride = KT; sp.out_keys = W->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->cur->w_thr.p + q0; sp.ovf = nullptr;
         if (ix->d_margin) { sp.shift_g = ix->cur->w_qg.p + q0; sp.shift_m_bits = ix->d_scalars + 4; }   // plain-score sample -> lower-bound units
         vdb::launch_thr_select(sp, nb, s);
 
@@ -696,16 +722,16 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         ix->cur->stats[3] += n;
 
         vdb::SelectParams mp{};
-        mp.keys = ix->cur->w_pool.p; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
-        mp.sub_counts = ix->cur->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl; mp.wg_major = 1;
-        mp.kk = kp; mp.out_keys = ix->cur->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
+        mp.keys = W->w_pool.p; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
+        mp.sub_counts = W->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl; mp.wg_major = 1;
+        mp.kk = kp; mp.out_keys = W->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
         mp.out_thr = nullptr; mp.ovf = d_ovf + q0; mp.summary = d_status + 1;
         vdb::launch_select(mp, nb, s);
 
         vdb::RerankParams rp{};
         rp.rows = ix->d_rows; rp.ld = ld; rp.dim = ix->dim; rp.n_rows = n;
         rp.qp = ix->cur->w_qp.p + (size_t)q0 * ld; rp.qnorm = ix->cur->w_qnorm.p + q0; rp.nd = ix->d_nd; rp.row_ids = ix->d_row_ids;
-        rp.rowmask = d_rowmask; rp.cand = ix->cur->w_cand.p; rp.cand_stride = kp; rp.cand_cnt = d_cand_cnt; rp.kp = kp;
+        rp.rowmask = d_rowmask; rp.cand = W->w_cand.p; rp.cand_stride = kp; rp.cand_cnt = d_cand_cnt; rp.kp = kp;
         rp.metric = ix->metric; rp.k = (uint32_t)k; rp.eps_coef = eps; rp.nd2max_bits = ix->d_scalars;
         rp.out_ids = d_out_ids + (size_t)q0 * k; rp.out_dists = d_out_dists + (size_t)q0 * k;
         rp.out_counts = d_out_counts + q0; rp.out_stride = (uint32_t)k; rp.cert = d_cert + q0; rp.status = d_status;
@@ -717,18 +743,22 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         if (ix->kn.kp_first) rp.kp_first = ix->kn.kp_first;
         const bool dump_depth = ix->kn.rr_depth;
         if (dump_depth) {
-            if ((rc = ix->cur->w_depth.ensure(SUPER))) return rc;
-            rp.depth = ix->cur->w_depth.p;
+            if ((rc = W->w_depth.ensure(SUPER))) return rc;
+            rp.depth = W->w_depth.p;
         }
         vdb::launch_rerank(rp, nb, s);
         if (dump_depth) {
             std::vector<uint32_t> dep(nb);
-            HIP_TRY(hipMemcpyAsync(dep.data(), ix->cur->w_depth.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(dep.data(), W->w_depth.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             std::sort(dep.begin(), dep.end());
             fprintf(stderr, "[vdb] re-rank depth of %u queries: min %u  p25 %u  median %u  p75 %u  p95 %u  max %u  (first round %u)\n", nb,
                     dep[0], dep[nb / 4], dep[nb / 2], dep[(size_t)nb * 3 / 4], dep[(size_t)nb * 95 / 100], dep[nb - 1], rp.kp_first);
         }
+    }
+    if (alt) {                                                   // the caller's stream continues behind BOTH chains
+        HIP_TRY(hipEventRecord(ix->ev_pass[1], Sv[1]));
+        HIP_TRY(hipStreamWaitEvent(s, ix->ev_pass[1], 0));
     }
     return VDB_OK;
 }
@@ -827,7 +857,7 @@ int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo
 // one of the cases answered completely here (empty store, k = 0, k too large for the MFMA tiers).
 int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, const uint64_t* d_idmask,
                  size_t mask_bits, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
-                 hipStream_t user_stream) {
+                 hipStream_t user_stream, bool allow_alt = false) {
     int rc;
     ix->cur->ctx.pending = false;
     if ((rc = set_device(ix))) return rc;
@@ -944,7 +974,7 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
         ix->cur->stats[8] = 1;
         ix->cur->stats[5] = kp16;
         if ((rc = pass_bf16(ix, s, nq32, k, pl16, d_rowmask, d_out_ids, d_out_dists, d_out_counts, d_cert, d_ovf, d_status,
-                            reinterpret_cast<float*>(d_ovf + nq32))))
+                            reinterpret_cast<float*>(d_ovf + nq32), allow_alt)))
             return rc;
     } else {
         if ((rc = pass_f32(ix, s, ix->cur->w_qp.p, ix->cur->w_qnorm.p, ix->cur->w_thr.p, nq32, k, kp, d_rowmask, d_out_ids, d_out_dists,
@@ -1132,7 +1162,9 @@ int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, 
     // a synchronous search takes a context no submitted search is using
     ix->cur = ix->wsv[0].busy ? &ix->wsv[1] : &ix->wsv[0];
     if (ix->cur->busy) return fail(VDB_ERR_INVALID_ARGUMENT, "two submitted searches are in flight on this handle: wait for one first");
-    int rc = search_part1(ix, d_q, nq, dim, k, d_idmask, mask_bits, d_out_ids, d_out_dists, d_out_counts, user_stream);
+    // (the other workspace may serve the alternating passes of a large batch: the handle mutex is held until part 2 is done,
+    // so no submit can claim it meanwhile)
+    int rc = search_part1(ix, d_q, nq, dim, k, d_idmask, mask_bits, d_out_ids, d_out_dists, d_out_counts, user_stream, !in_flight(ix));
     if (rc) { ix->cur->ctx.pending = false; publish_stats(ix); ix->cur = &ix->wsv[0]; return rc; }
     rc = search_part2(ix, nullptr);
     publish_stats(ix);
@@ -1231,6 +1263,7 @@ void vdb_flat_destroy(vdb_flat_index* ix) {
     if (ix->h_pout) (void)hipHostFree(ix->h_pout);
     if (ix->ev0) { (void)hipEventDestroy(ix->ev0); (void)hipEventDestroy(ix->ev1); }
     if (ix->ev_order) (void)hipEventDestroy(ix->ev_order);
+    for (int t = 0; t < 2; ++t) if (ix->ev_pass[t]) (void)hipEventDestroy(ix->ev_pass[t]);
     (void)hipStreamDestroy(ix->stream);
     delete ix;
 }
@@ -1460,7 +1493,7 @@ int vdb_flat_search_batch_device_begin(vdb_flat_index* ix, const float* d_querie
     if (in_flight(ix)) { ix->mu.unlock(); return refuse_in_flight(); }
     ix->cur = &ix->wsv[0];
     // (the handle is locked by hand here: an exception must not skip the unlock below)
-    int rc = guarded([&]() -> int { return search_part1(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts, (hipStream_t)stream); });
+    int rc = guarded([&]() -> int { return search_part1(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts, (hipStream_t)stream, true); });
     if (rc == VDB_OK && d_code) {
         hipStream_t s = stream ? (hipStream_t)stream : ix->stream;
         if (ix->cur->ctx.pending) vdb::launch_write_code(ix->cur->w_flags.p, d_code, s);
