@@ -208,7 +208,7 @@ int vdb_flat_last_stats(const vdb_flat_index *h, uint64_t out[8]);
  *  [10] [11] [12] host clock of the call, ns: first tier enqueued / its flags on the host / return
  *  [13] queries answered by the re-threshold pass (a second screening pass whose thresholds are the score cuts that the
  *       k-th exact distances of the first pass imply; every key under the cut is re-ranked)
- *  [14] (unused, 0)
+ *  [14] 1 when the screening pass read the bf16 shadow rows (vdb_flat_set_shadow)
  *  [15] 1 when the library is the DIAGNOSTICS build (-DVDB_DIAG) and one of its environment knobs is set: such a run
  *       is not covered by the exactness guarantee.  Always 0 in the release library, which reads no environment.
  * With the screening tier on, [4] [5] [7] describe ITS sample, k' and kernel time. */
@@ -221,6 +221,17 @@ int vdb_flat_last_stats_ex(const vdb_flat_index *h, uint64_t *out, size_t n);
  *  0: the f32-input MFMA tier only (v_mfma_f32_32x32x2_f32, arithmetic-bound), then the exact scan.
  */
 int vdb_flat_set_screen(vdb_flat_index *h, int mode);
+
+/*
+ * Opt-in bf16 SHADOW of the rows for the screening pass (no reference counterpart; results are identical with and without
+ * it).  on = 1: the index keeps, next to the f32 rows, their bf16 roundings (+50 % device memory: 2 bytes per element on top
+ * of 4) -- exactly the values the screening kernel otherwise produces in registers -- and the filter pass streams THOSE:
+ * half the HBM bytes per batch (csrc/kernels_fused_s16.hip).  The exact re-rank, the f32 tier and the exact scan keep
+ * reading the f32 rows, so the returned ids and distances do not change by a bit.  Used when the padded row length is a
+ * multiple of 64 elements (otherwise the f32-row pass runs as before).  Existing rows are converted by this call, later
+ * adds at their flush.  on = 0 frees the shadow.  last_stats_ex()[14] = 1 when the last search used it.
+ */
+int vdb_flat_set_shadow(vdb_flat_index *h, int on);
 
 /* Test hook (no reference counterpart; results are identical whatever the flags): force the hand-over of queries to
  * the slower tiers so that every tier can be compared with every other on the same index.  Not read from the

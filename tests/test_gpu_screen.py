@@ -14,15 +14,29 @@ from conftest import load_package
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def vdb():
+_SHADOW = [False]
+
+
+@pytest.fixture(scope="module", params=["f32_rows", "bf16_shadow"])
+def vdb(request):
+    """Every test of this module runs twice: screening from the f32 rows (kernels_fused_bf16p.hip) and from the opt-in bf16
+    shadow copy (kernels_fused_s16.hip, vdb_flat_set_shadow on every index the tests build).  Expectations are the same --
+    the shadow changes which bytes the filter pass streams, never a result or a tier counter."""
     v = load_package()
     v.build()
-    return v
+    _SHADOW[0] = request.param == "bf16_shadow"
+    yield v
+    _SHADOW[0] = False
+
+
+def shadow_on():
+    return _SHADOW[0]
 
 
 def make_index(vdb, metric, rows, ids=None):
     ix = vdb.GpuFlatIndex(vdb.DistanceMetric(metric), keep_host_copy=False)
+    if shadow_on():
+        ix.set_shadow(True)                                       # before the first add: the store grows with its shadow
     ix.add_bulk(rows, ids=ids)
     return ix
 
@@ -75,6 +89,7 @@ def test_screen_tier_vs_oracle_and_f32_tier(vdb, metric, n, d, nq, k, dist):
     a, st, b = both_tiers(ix, q, k)
     assert st["bf16_screen"] == 1 and st["kprime"] == (512 if k > 48 else 256) and st["rows_scanned"] >= n, st
     assert st["pool_overflows"] == 0, st
+    assert st["shadow_rows"] == (1 if shadow_on() and ((d + 31) // 32) % 2 == 0 else 0), st
     assert same(a, b)
     check_oracle(metric, rows, q, k, a, sorted({0, nq // 2, nq - 1}))
 
@@ -244,3 +259,56 @@ def test_error_semantics_under_the_screen_tier(vdb):
     e.add(10**6, V([float("nan")] + [1.0] * 7))                           # NaN distance: the reference panics (flat_index.rs:62)
     with pytest.raises(vdb.VectorDbError):
         e.search(V([1.0] * 8), 3)
+
+
+def test_shadow_copy_follows_adds_growth_and_toggling(vdb):
+    """vdb_flat_set_shadow on a filled index converts the existing rows; later adds (including a reallocation of the
+    store) maintain the shadow; turning it off frees it.  The results never change."""
+    rng = np.random.default_rng(99)
+    n0, n1, d, nq, k = 70_000, 90_000, 100, 50, 10
+    rows = rng.standard_normal((n0 + n1, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    ix = vdb.GpuFlatIndex(vdb.DistanceMetric(1), keep_host_copy=False)
+    ix.add_bulk(rows[:n0])
+    base = ix.search_batch_arrays(q, k)
+    assert ix.last_stats()["shadow_rows"] == 0
+    ix.set_shadow(True)
+    r = ix.search_batch_arrays(q, k)
+    assert ix.last_stats()["shadow_rows"] == 1 and ix.last_stats()["bf16_screen"] == 1 and same(r, base)
+    ix.add_bulk(rows[n0:], first_id=n0)                       # grows the store: the shadow is reallocated and extended
+    r2 = ix.search_batch_arrays(q, k)
+    st = ix.last_stats()
+    assert st["shadow_rows"] == 1 and st["rows_scanned"] >= n0 + n1
+    check_oracle(1, rows, q, k, r2, [0, 17, nq - 1])
+    for j in range(0, 40):                                    # single adds through the host staging path
+        ix.add(10_000_000 + j, vdb.Vector(rows[j] * 1.5))
+    ix.remove(5)
+    r3 = ix.search_batch_arrays(q, k)
+    assert ix.last_stats()["shadow_rows"] == 1
+    ix.set_shadow(False)
+    r4 = ix.search_batch_arrays(q, k)
+    assert ix.last_stats()["shadow_rows"] == 0 and same(r3, r4)
+    ix.set_screen(0)
+    assert same(ix.search_batch_arrays(q, k), r4)
+
+
+def test_shadow_and_f32_rows_give_the_same_raw_screening_scores(vdb):
+    """The scores themselves, not only the results: every (query, row) key the production filter pass emits carries the same
+    f32 bits from the bf16 shadow as from the f32 rows (same roundings, same MFMA order per accumulator), for the plain
+    scores and for the lower-bound scores of Dot / Euclid, with a ragged last tile and tombstones."""
+    rng = np.random.default_rng(5)
+    n, d, nq = 66_000 + 77, 192, 19
+    rows = (rng.standard_normal((n, d)) * rng.uniform(0.1, 4.0, (n, 1))).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    for metric in (0, 1, 2):
+        ix = vdb.GpuFlatIndex(vdb.DistanceMetric(metric), keep_host_copy=False)
+        ix.add_bulk(rows)
+        for r in range(0, 2000, 3):
+            ix.remove(r)
+        for raw in (0, 1):                                        # the scores the tier ranks by (lower bounds under Dot / Euclid), the plain scores
+            a = ix.debug_screen_scores(q, raw=raw)
+            ix.set_shadow(True)
+            b = ix.debug_screen_scores(q, raw=raw)
+            ix.set_shadow(False)
+            sa, sb = a[0], b[0]
+            assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32)), (metric, raw)

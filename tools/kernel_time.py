@@ -18,6 +18,7 @@ for c in range((n + 124999) // 125000):
     ix.add_bulk_device(blk.data_ptr(), m, dim, first_id=c * 125000); del blk
 ix.flush()
 ix.set_screen(int(os.environ.get("KT_SCREEN", 1)))
+if os.environ.get("KT_SHADOW"): ix.set_shadow(True)
 q = gen_queries(B, dim, dev)
 ids = torch.empty((B, k), dtype=torch.int64, device=dev); ds = torch.empty((B, k), dtype=torch.float32, device=dev); cnt = torch.empty((B,), dtype=torch.int32, device=dev)
 def step(): ix.search_batch_device(q.data_ptr(), B, dim, k, ids.data_ptr(), ds.data_ptr(), cnt.data_ptr())
@@ -31,4 +32,4 @@ print("host us (enqueued, flags on host, total):", np.mean(hs, axis=0) / 1e3)
 ix.set_profile(True); ks = []
 for _ in range(10): step(); ks.append(ix.last_stats()["fused_kernel_ns"] / 1e6)
 st = ix.last_stats()
-print(f"step {ms:.3f} ms  kernel {np.mean(ks):.4f} ms (min {min(ks):.4f})  {4.0*n*dim/np.mean(ks)/1e9:.2f} TB/s  uncert {st['uncertified']} f32q {st['f32_tier_queries']} ovf {st['pool_overflows']}")
+print(f"shadow_rows {st['shadow_rows']}  step {ms:.3f} ms  kernel {np.mean(ks):.4f} ms (min {min(ks):.4f})  {4.0*n*dim/np.mean(ks)/1e9:.2f} TB/s  uncert {st['uncertified']} f32q {st['f32_tier_queries']} ovf {st['pool_overflows']}")

@@ -76,6 +76,9 @@ struct RowStatsParams {
     float* margin; float m_e, m_n, m_b, beta_shrink;
 };
 void launch_row_stats(const RowStatsParams& p, hipStream_t s);
+// bf16 shadow of rows [row_begin, row_end): v_cvt_pk_bf16_f32 (RNE) of every element of the padded row -- the rounding the
+// f32-row screening kernels apply to their fragments in registers
+void launch_rows_to_bf16(const float* rows, uint16_t* rows16, uint32_t ld, uint32_t row_begin, uint32_t row_end, hipStream_t s);
 
 // count live rows whose norm is exactly zero (Cosine: distance.rs:51-55)
 void launch_count_zero_live(const float* nd, const uint32_t* livemask, uint32_t n_rows,
@@ -167,6 +170,7 @@ void launch_fused_dma3(const FusedParams& p, uint32_t n_super, hipStream_t s);
 // ---------------------------------------------------------------- bf16 screening tier (kernels_fused_bf16.hip)
 struct FusedBf16Params {
     const float* rows; uint32_t ld; uint32_t n_rows;
+    const uint16_t* rows16;                            // bf16 shadow of `rows`, same pitch (kernels_fused_s16.hip; null unless vdb_flat_set_shadow and ld % 64 == 0)
     const uint16_t* qb;                                // [256][ld] bf16 queries of this pass (zero padded)
     const float* alpha; const float* beta;
     // non-null (Dot / Euclid): the kernels rank by the LOWER-BOUND score  fma(-qg[q], margin[row], fma(dot, alpha, beta)),
@@ -189,6 +193,7 @@ void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s);      // unpipel
 #endif
 void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s);
 void launch_fused_bf16p(const FusedBf16Params& p, hipStream_t s);     // kernels_fused_bf16p.hip: the filter pass, software-pipelined (default)
+void launch_fused_s16(const FusedBf16Params& p, hipStream_t s);       // kernels_fused_s16.hip: the filter pass over p.rows16 (ld % 64 == 0)
 uint32_t fused_bf16_tile_rows();
 uint32_t fused_bf16_subpools_per_query(uint32_t n_wg);
 uint32_t fused_bf16_sample_groups(uint32_t n_sample);

@@ -177,6 +177,26 @@ void launch_row_stats(const RowStatsParams& p, hipStream_t s) {
     hipLaunchKernelGGL(row_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p);
 }
 
+// bf16 shadow copy of the rows (vdb_flat_set_shadow): the same RNE conversion the f32-row screening kernels apply to
+// their fragments, done once at upload; 8 elements per thread
+__global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restrict__ rows, uint16_t* __restrict__ rows16,
+                                                           size_t first8, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const float4* src = reinterpret_cast<const float4*>(rows) + 2 * (first8 + i);
+    const float4 lo = src[0], hi = src[1];
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    auto pk = [](float x, float y) { f2 v = {x, y}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2)); };
+    uint4 o = {pk(lo.x, lo.y), pk(lo.z, lo.w), pk(hi.x, hi.y), pk(hi.z, hi.w)};
+    reinterpret_cast<uint4*>(rows16)[first8 + i] = o;
+}
+void launch_rows_to_bf16(const float* rows, uint16_t* rows16, uint32_t ld, uint32_t row_begin, uint32_t row_end, hipStream_t s) {
+    if (row_end <= row_begin) return;
+    const size_t first8 = (size_t)row_begin * ld / 8, n8 = (size_t)(row_end - row_begin) * ld / 8;   // ld is a multiple of 32
+    hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, rows, rows16, first8, n8);
+}
+
 __global__ __launch_bounds__(256) void count_zero_live_kernel(const float* nd, const uint32_t* livemask,
                                                               uint32_t n_rows, uint32_t* out) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;

@@ -184,6 +184,8 @@ struct vdb_flat_index {
     bool live_dirty = false;
 
     // device store
+    uint16_t* d_rows16 = nullptr;         // opt-in bf16 shadow of d_rows [cap_rows][ld] (vdb_flat_set_shadow), else null
+    bool shadow = false;
     float* d_rows = nullptr; float* d_nd = nullptr; float* d_alpha = nullptr; float* d_beta = nullptr;
     float* d_margin = nullptr;            // [cap] per-row error margin of the screening tier's lower-bound scores (Dot / Euclid; null under Cosine)
     uint64_t* d_row_ids = nullptr; uint32_t* d_live = nullptr; uint32_t* d_scalars = nullptr;  // [0]=nd2max bits [1]=zero count [2],[3]=max bf16 rounding error of a row (abs^2, rel^2)
@@ -236,6 +238,12 @@ int grow(Index* ix, uint32_t need_rows) {
     HIP_TRY(hipMalloc((void**)&lv, (size_t)cap / 8));
     hipStream_t s = ix->stream;
     uint32_t old = ix->n_uploaded;
+    uint16_t* r16 = nullptr;
+    if (ix->shadow) {
+        HIP_TRY(hipMalloc((void**)&r16, (size_t)cap * ix->ld * 2));
+        if (old && ix->d_rows16) HIP_TRY(hipMemcpyAsync(r16, ix->d_rows16, (size_t)old * ix->ld * 2, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemsetAsync((char*)r16 + (size_t)old * ix->ld * 2, 0, (size_t)(cap - old) * ix->ld * 2, s));
+    }
     if (old) {
         HIP_TRY(hipMemcpyAsync(rows, ix->d_rows, (size_t)old * row_bytes, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipMemcpyAsync(nd, ix->d_nd, (size_t)old * 4, hipMemcpyDeviceToDevice, s));
@@ -254,6 +262,8 @@ int grow(Index* ix, uint32_t need_rows) {
         (void)hipFree(ix->d_beta); (void)hipFree(ix->d_row_ids); (void)hipFree(ix->d_live);
         if (ix->d_margin) (void)hipFree(ix->d_margin);
     }
+    if (ix->d_rows16) (void)hipFree(ix->d_rows16);
+    ix->d_rows16 = r16;
     ix->d_margin = mg;
     ix->d_rows = rows; ix->d_nd = nd; ix->d_alpha = al; ix->d_beta = be; ix->d_row_ids = ids; ix->d_live = lv;
     ix->cap_rows = cap;
@@ -267,6 +277,8 @@ void free_store(Index* ix) {
         (void)hipFree(ix->d_beta); (void)hipFree(ix->d_row_ids); (void)hipFree(ix->d_live);
         if (ix->d_margin) (void)hipFree(ix->d_margin);
     }
+    if (ix->d_rows16) (void)hipFree(ix->d_rows16);
+    ix->d_rows16 = nullptr;
     ix->d_margin = nullptr;
     ix->d_rows = ix->d_nd = ix->d_alpha = ix->d_beta = nullptr;
     ix->d_row_ids = nullptr; ix->d_live = nullptr;
@@ -418,6 +430,7 @@ int flush(Index* ix) {
         vdb::RowStatsParams rp{ix->d_rows, ix->ld, ix->dim, first, n, ix->metric, ix->d_nd, ix->d_alpha,
                                ix->d_beta, ix->d_scalars, ix->d_margin, mp.m_e, mp.m_n, mp.m_b, mp.beta_shrink};
         vdb::launch_row_stats(rp, s);
+        if (ix->d_rows16) vdb::launch_rows_to_bf16(ix->d_rows, ix->d_rows16, ix->ld, first, n, s);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(s));   // pending is host memory about to be released
         ix->pending.clear();
@@ -463,6 +476,17 @@ int ensure_ranks(Index* ix) {
     HIP_TRY(hipStreamSynchronize(ix->stream));
     ix->rank_valid = true;
     return VDB_OK;
+}
+
+// The filter pass of the screening tier: over the bf16 shadow rows when the index keeps them (vdb_flat_set_shadow) and the
+// row pitch allows whole 128-byte row requests, else over the f32 rows.  Same scores either way, bit for bit.
+bool shadow_usable(const Index* ix) { return ix->d_rows16 && ix->ld % 64 == 0; }
+void launch_filter_pass(Index* ix, vdb::FusedBf16Params& fp, hipStream_t s) {
+    if (shadow_usable(ix)) { fp.rows16 = ix->d_rows16; vdb::launch_fused_s16(fp, s); return; }
+#ifdef VDB_DIAG
+    if (!ix->kn.fused_pipe) { vdb::launch_fused_bf16(fp, s); return; }
+#endif
+    vdb::launch_fused_bf16p(fp, s);
 }
 
 // bf16 screening tier: the select delivers up to 256 candidates per query, sorted by score, and the re-rank goes
@@ -707,11 +731,7 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         vdb::launch_thr_select(sp, nb, s);
 
         if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
-#ifdef VDB_DIAG
-        if (!ix->kn.fused_pipe) vdb::launch_fused_bf16(fp, s);
-        else
-#endif
-        vdb::launch_fused_bf16p(fp, s);
+        launch_filter_pass(ix, fp, s);
         if (ix->profile) {
             HIP_TRY(hipEventRecord(ix->ev1, s));
             HIP_TRY(hipEventSynchronize(ix->ev1));
@@ -812,11 +832,7 @@ int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
         fp.margin = ix->d_margin; fp.qg = ix->d_margin ? ix->cur->w2_qg.p + q0 : nullptr;
         fp.thr = ix->cur->w2_thr.p + q0; fp.pool = ix->cur->w_pool.p; fp.pool_cnt = ix->cur->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
-#ifdef VDB_DIAG
-        if (!ix->kn.fused_pipe) vdb::launch_fused_bf16(fp, s);
-        else
-#endif
-        vdb::launch_fused_bf16p(fp, s);
+        launch_filter_pass(ix, fp, s);
         ix->cur->stats[3] += n;
         vdb::SelectParams mp{};
         mp.keys = ix->cur->w_pool.p; mp.sub_counts = ix->cur->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl; mp.wg_major = 1;
@@ -867,6 +883,7 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
     // events bracket them); the workspace is protected by the handle mutex and the final sync
     hipStream_t s = user_stream ? user_stream : ix->cur->stream;
     memset(ix->cur->stats, 0, sizeof(ix->cur->stats));
+    ix->cur->stats[14] = shadow_usable(ix) ? 1u : 0u;   // the screening pass reads the bf16 shadow rows
     ix->cur->stats[15] = ix->kn.any ? 1u : 0u;          // diagnostics build with a knob set: the run is NOT covered by the exactness guarantee
     const auto t_entry = std::chrono::steady_clock::now();
     auto since = [&]() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_entry).count(); };
@@ -1353,6 +1370,7 @@ int vdb_flat_add_bulk_device(vdb_flat_index* ix, const uint64_t* ids, uint64_t f
     vdb::RowStatsParams rp{ix->d_rows, ix->ld, ix->dim, first, first + (uint32_t)n, ix->metric, ix->d_nd,
                            ix->d_alpha, ix->d_beta, ix->d_scalars, ix->d_margin, mp.m_e, mp.m_n, mp.m_b, mp.beta_shrink};
     vdb::launch_row_stats(rp, s);
+    if (ix->d_rows16) vdb::launch_rows_to_bf16(ix->d_rows, ix->d_rows16, ix->ld, first, first + (uint32_t)n, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     ix->n_uploaded = first + (uint32_t)n;
@@ -1838,7 +1856,7 @@ int vdb_flat_debug_screen_scores(vdb_flat_index* ix, const float* queries, size_
     fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->cur->w_qb.p; fp.alpha = ix->d_alpha; fp.beta = ix->d_beta;
     fp.margin = lb ? ix->d_margin : nullptr; fp.qg = lb ? ix->cur->w_qg.p : nullptr;
     fp.rowmask = ix->d_live; fp.thr = ix->cur->w_thr.p; fp.pool = ix->cur->w_pool.p; fp.pool_cnt = ix->cur->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
-    vdb::launch_fused_bf16p(fp, s);                                              // the PRODUCTION filter pass
+    launch_filter_pass(ix, fp, s);                                                // the PRODUCTION filter pass (shadow rows if enabled)
     vdb::launch_pool_to_dense(ix->cur->w_pool.p, ix->cur->w_subcnt.p, n_sub, capl, (uint32_t)nq, n, ix->cur->w_dbg.p, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_scores, ix->cur->w_dbg.p, nq * (size_t)n * 4, hipMemcpyDeviceToHost, s));
@@ -1914,6 +1932,31 @@ int vdb_flat_debug_cert_probe(vdb_flat_index* ix, const uint32_t* qi, const floa
         hipStreamSynchronize(s) != hipSuccess)
         return done(fail(VDB_ERR_DEVICE, "cert probe failed"));
     return done(VDB_OK);
+    });
+}
+
+int vdb_flat_set_shadow(vdb_flat_index* ix, int on) {
+    return guarded([&]() -> int {
+    if (!ix || on < 0 || on > 1) return fail(VDB_ERR_INVALID_ARGUMENT, "on must be 0 or 1");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (in_flight(ix)) return refuse_in_flight();
+    HIP_TRY(hipSetDevice(ix->device));
+    int rc;
+    if ((rc = flush(ix))) return rc;
+    if (!on) {
+        if (ix->d_rows16) { HIP_TRY(hipStreamSynchronize(ix->stream)); (void)hipFree(ix->d_rows16); }
+        ix->d_rows16 = nullptr; ix->shadow = false;
+        return VDB_OK;
+    }
+    ix->shadow = true;
+    if (!ix->d_rows16 && ix->cap_rows) {
+        HIP_TRY(hipMalloc((void**)&ix->d_rows16, (size_t)ix->cap_rows * ix->ld * 2));
+        HIP_TRY(hipMemsetAsync(ix->d_rows16, 0, (size_t)ix->cap_rows * ix->ld * 2, ix->stream));
+        vdb::launch_rows_to_bf16(ix->d_rows, ix->d_rows16, ix->ld, 0, ix->n_uploaded, ix->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+    }
+    return VDB_OK;
     });
 }
 

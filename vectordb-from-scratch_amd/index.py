@@ -277,7 +277,7 @@ class GpuFlatIndex(Index):
         self._L.vdb_flat_last_stats_ex(self._h, out, 16)
         keys = ["mfma_queries", "exact_queries", "pool_overflows", "rows_scanned", "sample_rows", "kprime",
                 "uncertified", "fused_kernel_ns", "bf16_screen", "f32_tier_queries", "host_enqueued_ns",
-                "host_flags_ns", "host_total_ns", "rethreshold_queries", "reserved14", "diag_knobs_active"]
+                "host_flags_ns", "host_total_ns", "rethreshold_queries", "shadow_rows", "diag_knobs_active"]
         return dict(zip(keys, [int(v) for v in out]))
 
     def set_screen(self, mode):
@@ -287,6 +287,13 @@ class GpuFlatIndex(Index):
             _raise(rc)
 
     TIERS_NO_RETHRESHOLD, TIERS_FORCE_F32, TIERS_FORCE_EXACT = 1, 2, 4
+
+    def set_shadow(self, on=True):
+        """Opt-in bf16 shadow of the rows for the screening pass (include/vdb_flat.h: +50 % device memory, half the HBM bytes
+        per batch, results identical).  last_stats()["shadow_rows"] tells whether the last search used it."""
+        rc = self._L.vdb_flat_set_shadow(self._h, 1 if on else 0)
+        if rc != 0:
+            _raise(rc)
 
     def set_tiers(self, flags):
         """Test hook: force the hand-over of queries to the slower tiers (VDB_TIERS_*).  Results are identical."""
