@@ -83,13 +83,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const uint32_t KH = ld / 32;                                        // half-stages per tile (even)
     const uint32_t rowb = ld * 2;                                       // bytes per shadow row
 
-    // ---- the rows this workgroup covers: whole tiles, dealt out as in the f32-row kernel (same sub-pools, same keys)
+    // ---- the rows this workgroup covers: whole tiles dealt round-robin, as in the f32-row kernel (same sub-pools, same keys)
     const uint32_t nblk = (p.n_rows + TR - 1) / TR;
-    const uint32_t b0 = (uint32_t)(((uint64_t)blockIdx.x * nblk) / p.n_wg);
-    const uint32_t b1 = (uint32_t)(((uint64_t)(blockIdx.x + 1) * nblk) / p.n_wg);
-    const uint32_t r0 = b0 * TR;
-    const uint32_t r1 = (b1 * TR < p.n_rows) ? b1 * TR : p.n_rows;
-    const uint32_t ntiles = r0 < r1 ? (r1 - r0 + TR - 1) / TR : 0;
+    const uint32_t r0 = blockIdx.x * TR;
+    const uint32_t r1 = p.n_rows;
+    const uint32_t ntiles = blockIdx.x < nblk ? (nblk - blockIdx.x + p.n_wg - 1) / p.n_wg : 0;
+    const uint32_t TS = p.n_wg * TR;                                    // rows between consecutive tiles of this workgroup
 
     uint32_t q_of[QT];
     uint64_t* pool[QT];
@@ -137,7 +136,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     uint32_t ft = 0, fk = 0, fq = 0;
     const char* baseR = rows_b + (size_t)(r0 + 64 * w) * rowb;
     const char* baseQ = bbase + (4 * w) * 1024;
-    const size_t tile_jump = (size_t)TR * rowb - (size_t)(KS64 - 1) * 128;
+    const size_t tile_jump = (size_t)TS * rowb - (size_t)(KS64 - 1) * 128;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
     const uint32_t slotR0 = lds0 + R_OFF + (8 * w) * 1024, slotQ0 = lds0 + Q_OFF + (4 * w) * 1024;
     auto adv_rows = [&]() {
@@ -170,7 +169,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // row constants of a tile, one tile ahead (4 bytes per lane): wave w fetches those of tile rows 64w..64w+63
     auto issue_consts = [&](uint32_t t) {
         const uint32_t par = t & 1u;
-        uint32_t row = r0 + t * TR + 64 * w + lane;
+        uint32_t row = r0 + t * TS + 64 * w + lane;
         row = row > last_row ? last_row : row;
         VDB_DMA4(p.alpha + row, sAlpha + par * TR + 64 * w);
         VDB_DMA4(p.beta + row, sBeta + par * TR + 64 * w);
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
         if (HF == 1 && ks == KH - 1 && !(kDiag && (p.ablate & 8u))) {   // (KH is even: a tile ends on an odd half-stage)
             const uint32_t par = tile & 1u;
-            const uint32_t tr0 = r0 + tile * TR;
+            const uint32_t tr0 = r0 + tile * TS;
             // eligibility of this wave's 128 rows: two ballots over (in range) & (mask bit of the row)
             unsigned long long val[2];
 #pragma unroll

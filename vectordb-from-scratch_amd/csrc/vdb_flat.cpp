@@ -499,7 +499,11 @@ struct Bf16Plan { uint32_t kp = 0, S = 0, shift = 0, kt = 0; };
 Bf16Plan plan_bf16(const vdb_flat_index* ix, uint32_t n, size_t k) {
     Bf16Plan pl;
     if (n < BF16_MIN_ROWS || k > 112) return pl;
-    const uint32_t want_kt = std::min<uint32_t>(128u, round_up((uint32_t)k + 22u, 32u));
+    // threshold rank: at least kt rows pass the filter, about kt * n / S are expected to (k = 10 at 1M rows: 16 -> ~244 keys per
+    // query).  The re-rank certifies against the score of the first candidate it did NOT re-rank, so what the rank has to
+    // provide is a pool a few times deeper than the first round (k + 38), not a margin: 16 instead of 32 halves the appends
+    // of the filter pass (its epilogue's rare path, ~12 us per launch at config 2) at the same first-round certification
+    const uint32_t want_kt = std::min<uint32_t>(128u, round_up((uint32_t)k + 6u, 16u));
     uint64_t S = std::min<uint64_t>(65536u, std::max<uint64_t>(16384u, pow2_ceil((uint64_t)n / 16u)));
     if (ix->kn.sample16) S = pow2_ceil(std::max(256u, ix->kn.sample16));
     while (S / 256u < want_kt && 2 * S <= n / 2) S *= 2;
