@@ -22,6 +22,7 @@ Prints ONE JSON line on rank 0 (the driver contract) with
                     binding one named; "traffic" = PMC HBM bytes per launch of the profiled run the line cites;
   "f32_exact_tier"  the same index and queries through the f32-input MFMA tier only (the contract's f32 axis), results
                     compared bit for bit with the default path;
+  "shadow_rows"     the same index with the opt-in bf16 shadow of the rows (+50 % memory, half the streamed bytes), same results;
   "gauss_dataset"   the same size on unit-normalised Gaussian rows (the harder distribution of SURVEY 8(d));
   "cpu_baseline"    the CPU oracle = port of the reference algorithm, 1 core, bounded query sample.
 """
@@ -128,6 +129,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-f32-tier", action="store_true", help="skip the side measurement of the f32 MFMA tier")
     ap.add_argument("--no-gauss", action="store_true", help="skip the side measurement on unit-normalised Gaussian rows")
+    ap.add_argument("--no-shadow", action="store_true", help="skip the side measurement with the opt-in bf16 shadow rows (vdb_flat_set_shadow)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-batches-in-flight side measurement (keeps a profile's per-kernel averages synchronous)")
     ap.add_argument("--data", default="uniform", choices=["uniform", "gauss"], help="distribution of the HEADLINE index")
     ap.add_argument("--screen", type=int, default=1, help="1: bf16 screening tier first (default); 0: f32 MFMA tier only")
@@ -360,6 +362,30 @@ def main():
                      "in_flight": 2, "results_identical_to_synchronous_path": same,
                      "note": "vdb_flat_search_batch_device_submit / _wait: batch i+1 is submitted before batch i is waited for"}
 
+    # ---- opt-in bf16 shadow rows (vdb_flat_set_shadow): +50 % device memory, the filter pass streams 2 bytes per element.
+    # Same index, same queries, same results; reported beside the headline (which keeps the f32 rows), never as `value`.
+    shadow = None
+    if world == 1 and screened and not args.no_shadow and dim % 64 == 0 and mask_t is None:
+        index.set_shadow(True)
+        els, outs = timed(step, max(2, args.warmup // 2), args.steps)
+        sst = index.last_stats()
+        outs = tuple(t.clone() for t in outs)
+        ks = kernel_ms_of(index, step, n_prof, local_rows)
+        index.set_shadow(False)
+        sh_bytes = 2.0 * local_rows * dim + 2.0 * b_launch * dim
+        shadow = {"value": round(B * args.steps / els, 2), "unit": "queries/s", "ms_per_step": round(1e3 * els / args.steps, 4),
+                  "used": bool(sst.get("shadow_rows")), "extra_device_memory_bytes": int(2 * local_rows * dim),
+                  "results_identical_to_default_path": bool(torch.equal(outs[0], out[0]) and torch.equal(outs[1].view(torch.int32), out[1].view(torch.int32))),
+                  "kernel": "fused_s16_kernel (4 waves x 512 registers, 256 rows x 256 queries, 128 x 128 per wave with hand-allocated AccVGPR "
+                            "accumulators; bf16 rows 128 B per request into a 3 x 32 KB ring, queries into a 3 x 16 KB ring)",
+                  "kernel_ms": round(ks, 4),
+                  "axes": {"hbm": {"achieved": round(sh_bytes / (ks * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": round(sh_bytes / (ks * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": sh_bytes},
+                           "bf16_mfma": {"achieved": round(alg_flops / (ks * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": round(alg_flops / (ks * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}},
+                  "note": "neither axis binds alone: DMA only 0.26 ms, MFMA + fragment reads only 0.28 ms (the clock the chip holds under "
+                          "a dense bf16 MFMA loop), the per-tile epilogue ~0.09 ms with one wave per SIMD (DESIGN.md 4.2)"}
+
     # ---- the harder distribution of SURVEY 8(d): unit-normalised Gaussian rows, Gaussian queries, same size
     gauss = None
     if world == 1 and DATA == "uniform" and args.config == "c2" and not args.no_gauss:
@@ -470,6 +496,7 @@ def main():
             "path_stats": stats,
             "roofline": roofline,
             "pipelined_two_in_flight": pipelined,
+            "shadow_rows": shadow,
             "f32_exact_tier": f32_tier,
             "gauss_dataset": gauss,
             "pcie_inclusive": host_io,

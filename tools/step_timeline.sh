@@ -2,7 +2,7 @@
 # (rocprofv3 --kernel-trace only; medians over the timed steps)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/tl
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python bench.py --steps 60 --warmup 10 --no-cpu --no-f32-tier --no-gauss --no-pipelined > gpurun_out/tl.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -- python bench.py --steps 60 --warmup 10 --no-cpu --no-f32-tier --no-gauss --no-pipelined --no-shadow > gpurun_out/tl.log 2>&1
 tail -c 200 gpurun_out/tl.log
 python - <<'PY'
 import csv, glob, statistics as st

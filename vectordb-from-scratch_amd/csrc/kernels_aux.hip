@@ -88,6 +88,60 @@ __device__ __forceinline__ float fold_sqdiff(const float* __restrict__ q, const 
     return s;
 }
 
+// The same folds over a SLICE of the pair, resumed from a partial sum: fold(q, x, d) == part(q + d1, x + d1, d - d1, part(q, x, d1, 0))
+// for any d1 that is a multiple of 16 (the same sequence of roundings, element by element) -- rerank_kernel's K slices.
+__device__ __forceinline__ float fold_dot_part(const float* __restrict__ q, const float* __restrict__ x, uint32_t d, float s) {
+    uint32_t i = 0;
+    for (; i + 16 <= d; i += 16) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const float4*>(q + i + 4 * u);
+            b[u] = *reinterpret_cast<const float4*>(x + i + 4 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s = __fadd_rn(s, __fmul_rn(a[u].x, b[u].x));
+            s = __fadd_rn(s, __fmul_rn(a[u].y, b[u].y));
+            s = __fadd_rn(s, __fmul_rn(a[u].z, b[u].z));
+            s = __fadd_rn(s, __fmul_rn(a[u].w, b[u].w));
+        }
+    }
+    for (; i < d; ++i) s = __fadd_rn(s, __fmul_rn(q[i], x[i]));
+    return s;
+}
+__device__ __forceinline__ float fold_sqdiff_part(const float* __restrict__ q, const float* __restrict__ x, uint32_t d, float s) {
+    uint32_t i = 0;
+    for (; i + 16 <= d; i += 16) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const float4*>(q + i + 4 * u);
+            b[u] = *reinterpret_cast<const float4*>(x + i + 4 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float t;
+            t = __fsub_rn(a[u].x, b[u].x); s = __fadd_rn(s, __fmul_rn(t, t));
+            t = __fsub_rn(a[u].y, b[u].y); s = __fadd_rn(s, __fmul_rn(t, t));
+            t = __fsub_rn(a[u].z, b[u].z); s = __fadd_rn(s, __fmul_rn(t, t));
+            t = __fsub_rn(a[u].w, b[u].w); s = __fadd_rn(s, __fmul_rn(t, t));
+        }
+    }
+    for (; i < d; ++i) { float t = __fsub_rn(q[i], x[i]); s = __fadd_rn(s, __fmul_rn(t, t)); }
+    return s;
+}
+// the distance from the finished fold (s = sum of squared differences under Euclid, the dot product otherwise)
+__device__ __forceinline__ float distance_from_fold(int metric, float s, float qn, float xn) {
+    if (metric == EUCLID) return __builtin_sqrtf(s);
+    if (metric == DOT) return -s;
+    float den = __fmul_rn(qn, xn);                 // norm1 * norm2   distance.rs:58
+    float sim = __fdiv_rn(s, den);
+    if (sim < -1.0f) sim = -1.0f;                  // f32::clamp keeps NaN
+    if (sim > 1.0f) sim = 1.0f;
+    return __fsub_rn(1.0f, sim);
+}
+
 // DistanceMetric::distance (distance.rs:20-33) for one (query, row) pair.
 // qn / xn are the exact-order norms of query and row (only read under Cosine).
 __device__ __forceinline__ float exact_distance(int metric, const float* __restrict__ q,
@@ -824,6 +878,13 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
     __shared__ uint32_t sAnyNan, sNanKey, sNext, sRealW[RR_THREADS / 64];
     __shared__ CertConsts sCert;
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef VDB_DIAG
+    // phase stamps for tools/rerank_depth.sh (diagnostics build, VDB_RR_DEPTH): p.depth[gridDim.x .. ] as 8 x u64 per query
+#define VDB_STAMP(PH) if (p.depth && tid == 0) reinterpret_cast<uint64_t*>(p.depth + 256)[(size_t)q * 8 + (PH)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define VDB_STAMP(PH)
+#endif
+    VDB_STAMP(0)
     const uint32_t cnt = p.cand_cnt[q] < p.kp ? p.cand_cnt[q] : p.kp;
     const uint64_t* cand = p.cand + (size_t)q * p.cand_stride;
     if (tid == 0) { sAnyNan = 0; sNanKey = 0; sNext = 0; }
@@ -841,19 +902,17 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
         sDist[tid] = 0xffffffffu;
         sId[tid] = ~0ull;
     }
-    // the query row in LDS; row stride padded so that 16 lanes' b128 reads tile the banks
+    // the query row in LDS, then the slice area
     const uint32_t dimp = (p.dim + 3) & ~3u;
-    const uint32_t ldp = p.lds_row_stride;
-    const uint32_t chunk = p.lds_chunk;
+    const uint32_t area = p.lds_chunk;                            // floats available for candidate slices
     float* sQ = sRows;
-    float* sR = sRows + ldp;
+    float* sR = sRows + p.lds_row_stride;
     const float* gq = p.qp + (size_t)q * p.ld;                    // zero padded up to ld >= dimp
     for (uint32_t i = tid * 4; i < dimp; i += RR_THREADS * 4) *reinterpret_cast<float4*>(sQ + i) = *reinterpret_cast<const float4*>(gq + i);
     __syncthreads();
-    const uint32_t vpr = dimp / 4;                                // float4 per row
-    const uint32_t bpr = (vpr + 63) / 64;                         // 64-lane blocks per row
     const uint32_t nwaves = RR_THREADS / 64;
     const float qn_f = p.qnorm[q];
+    VDB_STAMP(1)
 
     uint32_t processed = 0;
     uint32_t target = cnt < p.kp_first ? cnt : p.kp_first;
@@ -862,30 +921,50 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
     bool cut_ok = false;                                          // a k-th exact distance exists and no NaN / ineligible candidate was seen
     double cut_ek = 0.0;
     while (true) {
-        // ---- exact distances of candidates [processed, target)
-        for (uint32_t c0 = processed; c0 < target; c0 += chunk) {
-            const uint32_t nthis = (target - c0 < chunk) ? target - c0 : chunk;
-            // stage the chunk's rows by LDS-DMA (global_load_lds_dwordx4: 1 KB of a row per wave instruction, no VGPR
-            // round trip), every piece of the chunk in flight at once; the barrier's vmcnt(0) waits for them
-            for (uint32_t u = wv; u < nthis * bpr; u += nwaves) {
-                const uint32_t r = u / bpr, b = u % bpr, c4 = b * 64 + lane;
-                const uint32_t row = sRowIdx[c0 + r];
-                if (row != 0xffffffffu && c4 < vpr)
-                    __builtin_amdgcn_global_load_lds((rr_glb_t)(p.rows + (size_t)row * p.ld + 4 * c4),
-                                                     (rr_lds_t)(sR + (size_t)r * ldp + 256 * b), 16, 0, 0);
-            }
-            __syncthreads();
-            if (tid < nthis) {
-                const uint32_t row = sRowIdx[c0 + tid];
-                if (row != 0xffffffffu) {
-                    float dist = exact_distance(p.metric, sQ, sR + (size_t)tid * ldp, p.dim, qn_f, p.nd[row]);
-                    if (dist != dist) sAnyNan = 1u;
-                    sDist[c0 + tid] = f32_to_ordered(dist);
-                    sId[c0 + tid] = p.row_ids[row];
+        // ---- exact distances of candidates [processed, target): ALL of them at once, one thread per candidate, the rows
+        // staged through LDS in K SLICES as wide as the slice area allows for that many rows (48 rows of 768: one slice = the
+        // whole row; 96 rows: two slices of 384; 144 rows: three of 256).  A thread carries its partial sum from slice to
+        // slice in a register -- the fold is the reference's sequential one, element by element, whatever the slicing -- so
+        // the depth of a round is no longer capped by what fits into LDS as whole rows, and a round costs one staging
+        // latency per slice instead of one per 48 candidates.
+        {
+            const uint32_t n = target - processed;                  // <= RR_MAX
+            uint32_t W = n ? (area / n - 4u) & ~15u : 16u;          // slice width: a multiple of the fold's unroll, + the bank padding below
+            if (W > dimp) W = (dimp + 15u) & ~15u;
+            if (W < 16) W = 16;                                     // (the launcher sizes the area for 512 rows of 16 + 4)
+            const uint32_t Wp = W + ((W % 8 == 0) ? 4 : 0);         // row stride: 16 lanes' b128 reads tile the banks
+            const uint32_t myrow = tid < n ? sRowIdx[processed + tid] : 0xffffffffu;
+            float acc = 0.0f;
+            for (uint32_t k0 = 0; n && k0 < dimp; k0 += W) {
+                const uint32_t wlen = dimp - k0 < W ? dimp - k0 : W;           // floats of this slice (a multiple of 4)
+                const uint32_t vpr = wlen / 4, bpr = (vpr + 63) / 64;
+                // stage the slice by LDS-DMA (global_load_lds_dwordx4: 1 KB of a row per wave instruction, no VGPR round
+                // trip), every piece in flight at once; the barrier's vmcnt(0) waits for them
+                for (uint32_t u = wv; u < n * bpr; u += nwaves) {
+                    const uint32_t r = u / bpr, b = u % bpr, c4 = b * 64 + lane;
+                    const uint32_t row = sRowIdx[processed + r];
+                    if (row != 0xffffffffu && c4 < vpr)
+                        __builtin_amdgcn_global_load_lds((rr_glb_t)(p.rows + (size_t)row * p.ld + k0 + 4 * c4),
+                                                         (rr_lds_t)(sR + (size_t)r * Wp + 256 * b), 16, 0, 0);
                 }
+                __syncthreads();
+                if (myrow != 0xffffffffu) {
+                    const uint32_t flen = (k0 + wlen > p.dim) ? p.dim - k0 : wlen;   // the fold stops at dim, not at the padding
+                    acc = p.metric == EUCLID ? fold_sqdiff_part(sQ + k0, sR + (size_t)tid * Wp, flen, acc)
+                                             : fold_dot_part(sQ + k0, sR + (size_t)tid * Wp, flen, acc);
+                }
+                __syncthreads();
+            }
+            if (myrow != 0xffffffffu) {
+                const float dist = distance_from_fold(p.metric, acc, qn_f, p.nd[myrow]);
+                if (dist != dist) sAnyNan = 1u;
+                sDist[processed + tid] = f32_to_ordered(dist);
+                sId[processed + tid] = p.row_ids[myrow];
             }
             __syncthreads();
         }
+        if (processed == 0) { VDB_STAMP(2) }
+        VDB_STAMP(5)
         processed = target;
         // ---- bitonic sort of the first P >= processed (dist, id) pairs, ascending; unused slots hold the maximum
         uint32_t P = 32;
@@ -919,6 +998,7 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
                 }
         }
 #undef VDB_CEX
+        if (processed <= p.kp_first) { VDB_STAMP(3) }
         // number of real candidates so far (ineligible ones sorted to the end with id ~0)
         if (tid < RR_MAX) {
             unsigned long long b0 = __ballot(tid < processed && sId[tid] != ~0ull);
@@ -945,6 +1025,7 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
             }
             __syncthreads();
             const uint32_t m = sNext;
+            if (processed <= p.kp_first) { VDB_STAMP(4) }
             if (can_test && m == processed) { cert = 1; break; }   // certified at this depth
             if (!clean) { cert = 0; break; }                        // depth cannot repair a NaN score or an ineligible candidate
             if (can_test && m != 0xffffffffu) target = m;           // re-rank exactly up to the first certifying candidate
@@ -984,6 +1065,8 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
         }
         if (p.depth) p.depth[q] = processed;
     }
+    VDB_STAMP(6)
+#undef VDB_STAMP
 }
 // ---------------------------------------------------------------------------------------------
 // Exhaustive re-rank (the re-threshold pass): EVERY key of the query's list is re-ranked in the reference's
@@ -1095,17 +1178,16 @@ void launch_rerank_all(const RerankParams& p, uint32_t nq, hipStream_t s) {
 
 void launch_rerank(const RerankParams& p, uint32_t nq, hipStream_t s) {
     if (!nq) return;
-    // LDS plan: query row + `chunk` candidate rows of padded stride (chunk = largest power of two that fits)
+    // LDS plan: the query row, then a slice area for the candidate rows of a round (rerank_kernel sizes its K slices to it)
     RerankParams q = p;
     if (q.kp > RR_MAX) q.kp = RR_MAX;
     if (q.kp_first == 0 || q.kp_first > q.kp) q.kp_first = q.kp;
     if (q.kp_step == 0) q.kp_step = 32;
     uint32_t dimp = (p.dim + 3) & ~3u;
-    q.lds_row_stride = dimp + ((dimp % 8 == 0) ? 4 : 0);
-    uint32_t chunk = (uint32_t)std::min<size_t>(64, (150 * 1024) / ((size_t)q.lds_row_stride * 4));
-    chunk = chunk > 1 ? chunk - 1 : 1;                          // one slot is the query row; folds run on the lanes of ONE wave
-    q.lds_chunk = chunk;
-    size_t lds = (size_t)(chunk + 1) * q.lds_row_stride * 4;   // dim <= ~19000 fits with chunk = 1
+    q.lds_row_stride = dimp + 4;                                  // floats of the query row (start of the slice area)
+    const size_t avail = (size_t)150 * 1024 / 4 - q.lds_row_stride;            // dim <= 16384: at least 21 K floats = 512 rows of 40
+    q.lds_chunk = (uint32_t)avail;
+    size_t lds = ((size_t)q.lds_row_stride + q.lds_chunk) * 4;
     hipLaunchKernelGGL(rerank_kernel, dim3(nq), dim3(RR_THREADS), lds, s, q);
 }
 

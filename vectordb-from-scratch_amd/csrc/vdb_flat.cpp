@@ -767,15 +767,28 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         if (ix->kn.kp_first) rp.kp_first = ix->kn.kp_first;
         const bool dump_depth = ix->kn.rr_depth;
         if (dump_depth) {
-            if ((rc = W->w_depth.ensure(SUPER))) return rc;
+            if ((rc = W->w_depth.ensure(SUPER * 17))) return rc;      // depth[q], then 8 x 64-bit phase stamps per query
             rp.depth = W->w_depth.p;
         }
         vdb::launch_rerank(rp, nb, s);
         if (dump_depth) {
-            std::vector<uint32_t> dep(nb);
-            HIP_TRY(hipMemcpyAsync(dep.data(), W->w_depth.p, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+            std::vector<uint32_t> dep((size_t)SUPER * 17);
+            HIP_TRY(hipMemcpyAsync(dep.data(), W->w_depth.p, dep.size() * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            std::sort(dep.begin(), dep.end());
+            // phase stamps (s_memrealtime, 100 MHz): 0 start, 1 query row in LDS, 2 round 1 staged+folded, 3 sorted, 4 depth decided, 5 last round folded, 6 end
+            const uint64_t* st64 = reinterpret_cast<const uint64_t*>(dep.data() + SUPER);
+            uint64_t t0 = ~0ull;
+            for (uint32_t q = 0; q < nb; ++q) t0 = std::min(t0, st64[(size_t)q * 8]);
+            double med[7];
+            for (int ph = 0; ph < 7; ++ph) {
+                std::vector<double> v(nb);
+                for (uint32_t q = 0; q < nb; ++q) v[q] = (double)(st64[(size_t)q * 8 + ph] - t0) * 0.01;
+                std::sort(v.begin(), v.end());
+                med[ph] = v[nb / 2];
+                fprintf(stderr, "[vdb] re-rank phase %d at us: min %.2f median %.2f p90 %.2f max %.2f\n", ph, v[0], v[nb / 2], v[(size_t)nb * 9 / 10], v[nb - 1]);
+            }
+            (void)med;
+            std::sort(dep.begin(), dep.begin() + nb);
             fprintf(stderr, "[vdb] re-rank depth of %u queries: min %u  p25 %u  median %u  p75 %u  p95 %u  max %u  (first round %u)\n", nb,
                     dep[0], dep[nb / 4], dep[nb / 2], dep[(size_t)nb * 3 / 4], dep[(size_t)nb * 95 / 100], dep[nb - 1], rp.kp_first);
         }
