@@ -233,6 +233,16 @@ int vdb_flat_set_screen(vdb_flat_index *h, int mode);
  */
 int vdb_flat_set_shadow(vdb_flat_index *h, int on);
 
+/*
+ * The screening tier's SAMPLE CACHE (on by default; no reference counterpart; results identical either way).  The tier
+ * derives its per-query filter thresholds from the scores of S <= 65536 sample rows spread over the index.  With the cache
+ * the index keeps a compact bf16 copy of exactly those rows (S * padded dimension * 2 bytes: 100 MB beside a 3 GB index),
+ * rebuilt by the first search after rows were added, and the sample pass streams it instead of gathering the rows from
+ * the f32 store: half the bytes, contiguous.  Same roundings, same MFMA order -> the same thresholds, bit for bit.
+ * Used when the padded row length is a multiple of 64 elements.  on = 0 frees the copy and restores the f32 gather.
+ */
+int vdb_flat_set_sample_cache(vdb_flat_index *h, int on);
+
 /* Test hook (no reference counterpart; results are identical whatever the flags): force the hand-over of queries to
  * the slower tiers so that every tier can be compared with every other on the same index.  Not read from the
  * environment -- the release library has no getenv on any path. */
@@ -265,6 +275,8 @@ int vdb_flat_debug_screen_scores(vdb_flat_index *h, const float *queries, size_t
                                  float *out_scores, float *out_qinfo, double *out_consts);
 size_t vdb_flat_debug_rows(const vdb_flat_index *h); /* device rows incl. tombstoned ones (row i = i-th row ever added since the last reset) */
 int vdb_flat_debug_row_info(vdb_flat_index *h, float *out, size_t n_rows);
+/* the per-query filter thresholds of the screening tier as the LAST search on this handle derived them from its sample pass (first nq queries) */
+int vdb_flat_debug_last_thresholds(vdb_flat_index *h, float *out, size_t nq);
 int vdb_flat_debug_cert_probe(vdb_flat_index *h, const uint32_t *qi, const float *T, const float *ek, size_t n,
                               uint32_t *out);
 

@@ -312,3 +312,44 @@ def test_shadow_and_f32_rows_give_the_same_raw_screening_scores(vdb):
             ix.set_shadow(False)
             sa, sb = a[0], b[0]
             assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32)), (metric, raw)
+
+
+def test_sample_cache_gives_the_same_thresholds_and_results(vdb):
+    """The compact bf16 copy of the sample rows (default) against the f32 gather (vdb_flat_set_sample_cache(0)): the per-query
+    filter thresholds are the same f32 bits -- same roundings, same MFMA order, same group minima -- and so is everything
+    downstream; the copy follows adds (rebuilt by the next search), tombstones and an id mask."""
+    rng = np.random.default_rng(31)
+    n0, n1, d, nq, k = 100_000, 37_777, 128, 200, 10
+    rows = (rng.standard_normal((n0 + n1, d)) * rng.uniform(0.2, 3.0, (n0 + n1, 1))).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    for metric in (0, 1, 2):
+        ix = make_index(vdb, metric, rows[:n0])
+        for r in range(0, 5000, 11):
+            ix.remove(r)
+
+        def both(**kw):
+            ix.set_sample_cache(True)
+            a = ix.search_batch_arrays(q, k, **kw)
+            ta, sa = ix.debug_last_thresholds(nq), ix.last_stats()
+            ix.set_sample_cache(False)
+            b = ix.search_batch_arrays(q, k, **kw)
+            tb, sb = ix.debug_last_thresholds(nq), ix.last_stats()
+            ix.set_sample_cache(True)
+            assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32)), metric
+            assert np.all(np.isfinite(ta))
+            assert same(a, b)
+            for key in ("bf16_screen", "uncertified", "pool_overflows", "f32_tier_queries", "exact_queries", "rethreshold_queries", "sample_rows"):
+                assert sa[key] == sb[key], (key, sa[key], sb[key])
+            assert sa["bf16_screen"] == 1
+            return a
+
+        both()
+        ix.add_bulk(rows[n0:], first_id=n0)                       # more rows: other sample rows, the copy is rebuilt
+        r2 = both()
+        live = np.ones(n0 + n1, dtype=np.uint8)
+        live[0:5000:11] = 0
+        check_oracle(metric, rows, q, k, r2, [0, nq - 1], live=live)
+        mask = np.zeros(((n0 + n1 + 63) // 64,), dtype=np.uint64)  # an id mask: every third id
+        ids = np.arange(0, n0 + n1, 3)
+        np.bitwise_or.at(mask, ids // 64, np.uint64(1) << (ids % 64).astype(np.uint64))
+        both(id_mask=mask, mask_bits=n0 + n1)

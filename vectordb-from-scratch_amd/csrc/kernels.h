@@ -79,6 +79,9 @@ void launch_row_stats(const RowStatsParams& p, hipStream_t s);
 // bf16 shadow of rows [row_begin, row_end): v_cvt_pk_bf16_f32 (RNE) of every element of the padded row -- the rounding the
 // f32-row screening kernels apply to their fragments in registers
 void launch_rows_to_bf16(const float* rows, uint16_t* rows16, uint32_t ld, uint32_t row_begin, uint32_t row_end, hipStream_t s);
+// compact bf16 copy of the S = 2^shift sample rows of the screening tier: out[j] = bf16(rows[sample_row(j)]), j < S, the
+// mapping of the sample kernels (position (j & 255) * (S >> 8) + (j >> 8), row = (position * n_rows) >> shift)
+void launch_sample_to_bf16(const float* rows, uint32_t ld, uint32_t n_rows, uint32_t n_sample, uint32_t shift, uint16_t* out, hipStream_t s);
 
 // count live rows whose norm is exactly zero (Cosine: distance.rs:51-55)
 void launch_count_zero_live(const float* nd, const uint32_t* livemask, uint32_t n_rows,
@@ -194,6 +197,7 @@ void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s);      // unpipel
 void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s);
 void launch_fused_bf16p(const FusedBf16Params& p, hipStream_t s);     // kernels_fused_bf16p.hip: the filter pass, software-pipelined (default)
 void launch_fused_s16(const FusedBf16Params& p, hipStream_t s);       // kernels_fused_s16.hip: the filter pass over p.rows16 (ld % 64 == 0)
+void launch_sample_s16(const FusedBf16Params& p, hipStream_t s);      // the sample pass over a COMPACT bf16 copy of the sample rows (p.rows16 = the copy)
 uint32_t fused_bf16_tile_rows();
 uint32_t fused_bf16_subpools_per_query(uint32_t n_wg);
 uint32_t fused_bf16_sample_groups(uint32_t n_sample);

@@ -251,6 +251,27 @@ void launch_rows_to_bf16(const float* rows, uint16_t* rows16, uint32_t ld, uint3
     hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, rows, rows16, first8, n8);
 }
 
+__global__ __launch_bounds__(256) void sample_to_bf16_kernel(const float* __restrict__ rows, uint32_t ld8, uint32_t n_rows, uint32_t n_sample,
+                                                             uint32_t shift, uint16_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // 8 elements per thread
+    if (i >= (size_t)n_sample * ld8) return;
+    const uint32_t j = (uint32_t)(i / ld8), c8 = (uint32_t)(i % ld8);
+    const uint32_t pos = (j & 255u) * (n_sample >> 8) + (j >> 8);
+    const uint32_t row = (uint32_t)(((uint64_t)pos * n_rows) >> shift);
+    const float4* src = reinterpret_cast<const float4*>(rows + (size_t)row * ld8 * 8) + 2 * c8;
+    const float4 lo = src[0], hi = src[1];
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+    auto pk = [](float x, float y) { f2 v = {x, y}; return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2)); };
+    uint4 o = {pk(lo.x, lo.y), pk(lo.z, lo.w), pk(hi.x, hi.y), pk(hi.z, hi.w)};
+    reinterpret_cast<uint4*>(out)[i] = o;
+}
+void launch_sample_to_bf16(const float* rows, uint32_t ld, uint32_t n_rows, uint32_t n_sample, uint32_t shift, uint16_t* out, hipStream_t s) {
+    if (!n_sample || !n_rows) return;
+    const size_t n8 = (size_t)n_sample * (ld / 8);
+    hipLaunchKernelGGL(sample_to_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, rows, ld / 8, n_rows, n_sample, shift, out);
+}
+
 __global__ __launch_bounds__(256) void count_zero_live_kernel(const float* nd, const uint32_t* livemask,
                                                               uint32_t n_rows, uint32_t* out) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;

@@ -58,7 +58,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define VDB_MFMA(I, J, FA, FB)                                                                         \
     asm volatile("v_mfma_f32_32x32x16_bf16 a[%2:%3], %0, %1, a[%2:%3]"                               \
                  :: "v"(FA), "v"(FB), "n"(16 * (4 * (I) + (J))), "n"(16 * (4 * (I) + (J)) + 15) : VDB_ALL_AGPRS)
-#define VDB_ACC_READ(DST, I, J, R) asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(DST) : "n"(16 * (4 * (I) + (J)) + (R)))
+// (the AccVGPR clobber list on a READ keeps hipcc from parking values in "free" AccVGPRs across it -- it has no other way to
+// know that a[0:255] are taken; the Makefile checks the generated code for compiler-made AccVGPR accesses and scratch)
+#define VDB_ACC_READ(DST, I, J, R) asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(DST) : "n"(16 * (4 * (I) + (J)) + (R)) : VDB_ALL_AGPRS)
 #define VDB_Z1(N) asm volatile("v_accvgpr_write_b32 a[%0], 0" :: "n"(N) : VDB_ALL_AGPRS);
 #define VDB_Z4(N) VDB_Z1(N) VDB_Z1((N) + 1) VDB_Z1((N) + 2) VDB_Z1((N) + 3)
 #define VDB_Z16(N) VDB_Z4(N) VDB_Z4((N) + 4) VDB_Z4((N) + 8) VDB_Z4((N) + 12)
@@ -66,7 +68,11 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define VDB_ZERO_ACC { VDB_Z64(0) VDB_Z64(64) VDB_Z64(128) VDB_Z64(192) asm volatile("s_nop 7" ::: "memory"); }
 }  // namespace
 
-template <bool MARGIN>
+// SAMPLE = true: the sample pass over the COMPACT bf16 copy of the sample rows (p.rows16 = that copy, sample j at row j: the
+// rows the f32 sample pass gathers with 3 KB strides, here contiguous and half the bytes).  One tile per workgroup; the
+// epilogue keeps the smallest eligible score per (tile, row half, lane half) and query instead of filtering -- the same
+// groups, the same scores and therefore the same thresholds as kernels_fused_bf16.hip's sample mode.
+template <bool SAMPLE, bool MARGIN>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void fused_s16_kernel(FusedBf16Params p) {
     __shared__ __attribute__((aligned(16))) char smem[IMG_BYTES];
     __shared__ __attribute__((aligned(16))) float sAlpha[2 * TR];
@@ -84,11 +90,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const uint32_t rowb = ld * 2;                                       // bytes per shadow row
 
     // ---- the rows this workgroup covers: whole tiles dealt round-robin, as in the f32-row kernel (same sub-pools, same keys)
-    const uint32_t nblk = (p.n_rows + TR - 1) / TR;
+    const uint32_t nblk = ((SAMPLE ? p.n_sample : p.n_rows) + TR - 1) / TR;
     const uint32_t r0 = blockIdx.x * TR;
-    const uint32_t r1 = p.n_rows;
-    const uint32_t ntiles = blockIdx.x < nblk ? (nblk - blockIdx.x + p.n_wg - 1) / p.n_wg : 0;
-    const uint32_t TS = p.n_wg * TR;                                    // rows between consecutive tiles of this workgroup
+    const uint32_t r1 = SAMPLE ? p.n_sample : p.n_rows;
+    const uint32_t ntiles = SAMPLE ? 1u : (blockIdx.x < nblk ? (nblk - blockIdx.x + p.n_wg - 1) / p.n_wg : 0);
+    const uint32_t TS = SAMPLE ? TR : p.n_wg * TR;                      // rows between consecutive tiles of this workgroup
+    // sample index -> device row: positions spread evenly over the rows, consecutive positions in different tiles (see
+    // kernels_fused_bf16.hip)
+    auto sample_row_of = [&](uint32_t j) -> uint32_t {
+        const uint32_t pos = (j & 255u) * (p.n_sample >> 8) + (j >> 8);
+        return (uint32_t)(((uint64_t)pos * p.n_rows) >> p.sample_shift);
+    };
 
     uint32_t q_of[QT];
     uint64_t* pool[QT];
@@ -98,18 +110,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
     for (int j = 0; j < QT; ++j) {
         q_of[j] = wq * 128 + 32 * j + c;
+        sub[j] = 0; pool[j] = nullptr; thr[j] = 0.f; pcnt[j] = 0;
+        if (SAMPLE) continue;
         sub[j] = (((size_t)q_of[j] * p.n_wg + blockIdx.x) * 2 + wr) * 2 + h;
         pool[j] = p.pool + ((((size_t)blockIdx.x * TQ + q_of[j]) * 2 + wr) * 2 + h) * p.capl;
         thr[j] = p.thr[q_of[j]];
         if (kDiag && (p.ablate & 16u)) thr[j] = -__builtin_inff();
         asm volatile("" : "+v"(thr[j]));                                // consumed here: no ordinary load pending in the loop
-        pcnt[j] = 0;
     }
     if (ntiles == 0) {
 #pragma unroll
         for (int j = 0; j < QT; ++j) p.pool_cnt[sub[j]] = 0;
         return;
     }
+    if (SAMPLE && r0 >= r1) return;
     const uint32_t NS = ntiles * (KH / 2);                              // row stages (= pairs of half-stages) of this workgroup
     const uint32_t last_row = p.n_rows - 1;
     const char* __restrict__ rows_b = reinterpret_cast<const char*>(p.rows16);
@@ -170,6 +184,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     auto issue_consts = [&](uint32_t t) {
         const uint32_t par = t & 1u;
         uint32_t row = r0 + t * TS + 64 * w + lane;
+        if (SAMPLE) row = sample_row_of(row < p.n_sample ? row : p.n_sample - 1);     // (row was the sample index)
         row = row > last_row ? last_row : row;
         VDB_DMA4(p.alpha + row, sAlpha + par * TR + 64 * w);
         VDB_DMA4(p.beta + row, sBeta + par * TR + 64 * w);
@@ -290,11 +305,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const uint32_t par = tile & 1u;
             const uint32_t tr0 = r0 + tile * TS;
             // eligibility of this wave's 128 rows: two ballots over (in range) & (mask bit of the row)
-            unsigned long long val[2];
+            unsigned long long val[2] = {0ull, 0ull};
+            if (SAMPLE) {
+                // eligibility folded into beta: thread t owns tile row t; an ineligible row gets beta = +inf, so its scores are
+                // +inf (or NaN) and never a group minimum -- no per-element select in the scoring below
+                const uint32_t rt = tid;
+                const uint32_t sj = tr0 + rt < r1 ? tr0 + rt : r1 - 1;
+                const bool ok = tr0 + rt < r1 && ((sMaskW[par * TR + rt] >> (sample_row_of(sj) & 31)) & 1u);
+                if (!ok) sBeta[par * TR + rt] = __uint_as_float(0x7f800000u);
+                __syncthreads();
+            } else {
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const uint32_t rt = wr * 128 + 64 * m + lane;
-                val[m] = __ballot(tr0 + rt < r1 && ((sMaskW[par * TR + rt] >> (rt & 31)) & 1u));
+                for (int m = 0; m < 2; ++m) {
+                    const uint32_t rt = wr * 128 + 64 * m + lane;
+                    val[m] = __ballot(tr0 + rt < r1 && ((sMaskW[par * TR + rt] >> (rt & 31)) & 1u));       // (tr0 is a multiple of 32)
+                }
             }
             const float* al = sAlpha + par * TR + wr * 128 + 4 * h;
             const float* be = sBeta + par * TR + wr * 128 + 4 * h;
@@ -315,6 +340,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     thp[j] += (fabsf(thr[j]) + g * mm) * 6.0e-7f;
                 }
             }
+            float best[QT];                                             // sample mode: running group minima
+#pragma unroll
+            for (int j = 0; j < QT; ++j) best[j] = __uint_as_float(0x7f800000u);
             asm volatile("s_nop 7" ::: "memory");                       // the last MFMA of the k-step wrote a[240:255]; they are read last
 #define VDB_EPI_J(I, G4, J)                                                                            \
     {                                                                                                  \
@@ -324,6 +352,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const f32x2 p01 = {p0_, p1_}, p23 = {p2_, p3_};                                                \
         const f32x2 s01 = __builtin_elementwise_fma(p01, al01, be01), s23 = __builtin_elementwise_fma(p23, al23, be23); \
         const float s0 = s01.x, s1 = s01.y, s2 = s23.x, s3 = s23.y;                                    \
+        if (SAMPLE) {                                                                                  \
+            /* smallest score of the lane's rows; ineligible rows score +inf (their beta was replaced above), and v_min_f32 */ \
+            /* skips a NaN score: such a row is no witness for a threshold */                          \
+            best[J] = fminf(fminf(best[J], s0), s1); best[J] = fminf(fminf(best[J], s2), s3);          \
+            asm volatile("" : "+v"(best[J]));      /* computed HERE: left alone, hipcc sinks the min chains of three of the four */ \
+                                                   /* queries to the end of the epilogue and keeps 192 scores alive (spills) */ \
+        } else {                                                                                       \
         const float tp = thp[J];                                                                       \
         const unsigned long long m = __builtin_amdgcn_ballot_w64(!(s0 > tp)) | __builtin_amdgcn_ballot_w64(!(s1 > tp)) | \
                                      __builtin_amdgcn_ballot_w64(!(s2 > tp)) | __builtin_amdgcn_ballot_w64(!(s3 > tp));  \
@@ -342,6 +377,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 ++pcnt[J];                                                                             \
             }                                                                                          \
         }                                                                                              \
+        }                                                                                              \
     }
 #define VDB_EPI_G(I, G4)                                                                               \
     {                                                                                                  \
@@ -349,8 +385,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const float4 b4 = *reinterpret_cast<const float4*>(be + (I) * 32 + 8 * (G4));                  \
         const f32x2 al01 = {a4.x, a4.y}, al23 = {a4.z, a4.w}, be01 = {b4.x, b4.y}, be23 = {b4.z, b4.w}; \
         const uint32_t rt0 = rowt + 8 * (G4);                                                          \
-        VDB_EPI_J(I, G4, 0) VDB_EPI_J(I, G4, 1) VDB_EPI_J(I, G4, 2) VDB_EPI_J(I, G4, 3)                \
-        __builtin_amdgcn_sched_barrier(0);                                                             \
+        VDB_EPI_J(I, G4, 0) __builtin_amdgcn_sched_barrier(0); VDB_EPI_J(I, G4, 1) __builtin_amdgcn_sched_barrier(0);            \
+        VDB_EPI_J(I, G4, 2) __builtin_amdgcn_sched_barrier(0); VDB_EPI_J(I, G4, 3) __builtin_amdgcn_sched_barrier(0);            \
     }
 #define VDB_EPI_I(I)                                                                                   \
     {                                                                                                  \
@@ -362,6 +398,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #undef VDB_EPI_I
 #undef VDB_EPI_G
 #undef VDB_EPI_J
+            if (SAMPLE) {
+                // one group minimum per (tile, row half, lane half) and query; the key's low word only has to make the keys of
+                // one query distinct: the group index
+                const uint32_t g = ((blockIdx.x * 2 + wr) * 2 + h);
+#pragma unroll
+                for (int j = 0; j < QT; ++j)
+                    p.minkeys[(size_t)q_of[j] * p.minkey_stride + g] = best[j] < __uint_as_float(0x7f800000u) ? make_key(best[j], g) : EMPTY_KEY;
+            }
             VDB_ZERO_ACC
         }
         ++ks;
@@ -375,8 +419,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         run_half(H1{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the look-ahead fetches past the last stage target this workgroup's LDS
+    if (!SAMPLE) {
 #pragma unroll
-    for (int j = 0; j < QT; ++j) p.pool_cnt[sub[j]] = pcnt[j];
+        for (int j = 0; j < QT; ++j) p.pool_cnt[sub[j]] = pcnt[j];
+    }
 #undef VDB_DMA_SV
 #undef VDB_MFMA_DMA
 #undef VDB_MFMA4
@@ -387,8 +433,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 }
 
 void launch_fused_s16(const FusedBf16Params& p, hipStream_t s) {
-    if (p.margin) hipLaunchKernelGGL((fused_s16_kernel<true>), dim3(p.n_wg), dim3(NT), 0, s, p);
-    else hipLaunchKernelGGL((fused_s16_kernel<false>), dim3(p.n_wg), dim3(NT), 0, s, p);
+    if (p.margin) hipLaunchKernelGGL((fused_s16_kernel<false, true>), dim3(p.n_wg), dim3(NT), 0, s, p);
+    else hipLaunchKernelGGL((fused_s16_kernel<false, false>), dim3(p.n_wg), dim3(NT), 0, s, p);
+}
+
+// the sample pass over the compact bf16 sample copy (p.rows16): plain scores, as launch_sample_bf16
+void launch_sample_s16(const FusedBf16Params& p, hipStream_t s) {
+    const uint32_t stiles = (p.n_sample + TR - 1) / TR;
+    if (!stiles) return;
+    FusedBf16Params q = p;
+    q.margin = nullptr; q.qg = nullptr;
+    hipLaunchKernelGGL((fused_s16_kernel<true, false>), dim3(stiles), dim3(NT), 0, s, q);
 }
 
 }  // namespace vdb

@@ -184,6 +184,12 @@ struct vdb_flat_index {
     bool live_dirty = false;
 
     // device store
+    // compact bf16 copy of the screening tier's S sample rows (kernels_fused_s16.hip SAMPLE mode): +S*ld*2 bytes (3 % of a 1M-row
+    // index), rebuilt when rows were added; the sample pass then streams 100 MB of contiguous bf16 instead of gathering 200 MB of
+    // f32 rows.  Thresholds are identical (same roundings, same MFMA order).  vdb_flat_set_sample_cache(h, 0) turns it off.
+    uint16_t* d_sample16 = nullptr; size_t sample16_cap = 0;            // capacity in elements
+    uint32_t sample16_n = 0, sample16_S = 0;                            // what the copy was built for (rows uploaded, sample size)
+    bool sample_cache = true;
     uint16_t* d_rows16 = nullptr;         // opt-in bf16 shadow of d_rows [cap_rows][ld] (vdb_flat_set_shadow), else null
     bool shadow = false;
     float* d_rows = nullptr; float* d_nd = nullptr; float* d_alpha = nullptr; float* d_beta = nullptr;
@@ -279,6 +285,8 @@ void free_store(Index* ix) {
     }
     if (ix->d_rows16) (void)hipFree(ix->d_rows16);
     ix->d_rows16 = nullptr;
+    if (ix->d_sample16) (void)hipFree(ix->d_sample16);
+    ix->d_sample16 = nullptr; ix->sample16_cap = 0; ix->sample16_n = ix->sample16_S = 0;
     ix->d_margin = nullptr;
     ix->d_rows = ix->d_nd = ix->d_alpha = ix->d_beta = nullptr;
     ix->d_row_ids = nullptr; ix->d_live = nullptr;
@@ -702,6 +710,26 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         if ((rc = w->w_subcnt.ensure((size_t)SUPER * n_sub))) return rc;
         if ((rc = w->w_cnt.ensure(4 * SUPER + 16))) return rc;
     }
+    // the sample pass runs over the compact bf16 copy of the sample rows when the row pitch allows (rebuilt here, before the
+    // passes fork onto two streams, when rows were added since it was made -- mutators are refused while a search is in flight,
+    // so nobody else is reading it; with ANOTHER search in flight and a different key this one keeps the f32 gather)
+    bool sample_copy = ix->sample_cache && ld % 64 == 0 && !ix->kn.sample_block;
+    if (sample_copy && (ix->sample16_n != n || ix->sample16_S != S)) {
+        Workspace* o = (ix->cur == &ix->wsv[0]) ? &ix->wsv[1] : &ix->wsv[0];
+        if (o->busy) sample_copy = false;
+        else {
+            const size_t need = (size_t)S * ld;
+            if (ix->sample16_cap < need) {
+                if (ix->d_sample16) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(ix->d_sample16); ix->d_sample16 = nullptr; ix->sample16_cap = 0; }
+                HIP_TRY(hipMalloc((void**)&ix->d_sample16, need * 2));
+                ix->sample16_cap = need;
+            }
+            vdb::launch_sample_to_bf16(ix->d_rows, ld, n, S, pl.shift, ix->d_sample16, s);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s));                        // once per change of the rows: later searches on OTHER streams read it
+            ix->sample16_n = n; ix->sample16_S = S;
+        }
+    }
     if (alt) {                                                   // the other stream starts behind query_prep and the row mask
         if (!ix->ev_pass[0]) {
             HIP_TRY(hipEventCreateWithFlags(&ix->ev_pass[0], hipEventDisableTiming));
@@ -726,7 +754,11 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         fp.ablate = ix->kn.bf16_ablate;
         fp.n_sample = S; fp.sample_shift = pl.shift;
         fp.sample_block = ix->kn.sample_block ? (n / (S / 256u)) : 0u; fp.minkeys = W->w_dense.p; fp.minkey_stride = M;
-        vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);    // (the sample always reads the f32 rows)
+        if (sample_copy) {
+            vdb::FusedBf16Params sp16 = fp;
+            sp16.rows16 = ix->d_sample16;
+            vdb::launch_sample_s16(sp16, s);
+        } else vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);
 
         vdb::SelectParams sp{};
         sp.keys = W->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = KT;
@@ -1900,6 +1932,19 @@ int vdb_flat_debug_screen_scores(vdb_flat_index* ix, const float* queries, size_
 
 size_t vdb_flat_debug_rows(const vdb_flat_index* ix) { return ix ? ix->row_ids.size() : 0; }
 
+int vdb_flat_debug_last_thresholds(vdb_flat_index* ix, float* out, size_t nq) {
+    return guarded([&]() -> int {
+    if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (in_flight(ix)) return refuse_in_flight();
+    int rc;
+    if ((rc = set_device(ix))) return rc;
+    if (nq > ix->cur->w_thr.n) return fail(VDB_ERR_INVALID_ARGUMENT, "more queries than the last search prepared");
+    HIP_TRY(hipMemcpy(out, ix->cur->w_thr.p, nq * 4, hipMemcpyDeviceToHost));
+    return VDB_OK;
+    });
+}
+
 int vdb_flat_debug_row_info(vdb_flat_index* ix, float* out, size_t n_rows) {
     return guarded([&]() -> int {
     if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
@@ -1949,6 +1994,22 @@ int vdb_flat_debug_cert_probe(vdb_flat_index* ix, const uint32_t* qi, const floa
         hipStreamSynchronize(s) != hipSuccess)
         return done(fail(VDB_ERR_DEVICE, "cert probe failed"));
     return done(VDB_OK);
+    });
+}
+
+int vdb_flat_set_sample_cache(vdb_flat_index* ix, int on) {
+    return guarded([&]() -> int {
+    if (!ix || on < 0 || on > 1) return fail(VDB_ERR_INVALID_ARGUMENT, "on must be 0 or 1");
+    std::lock_guard<std::mutex> g(ix->mu);
+    if (in_flight(ix)) return refuse_in_flight();
+    ix->sample_cache = on != 0;
+    if (!on && ix->d_sample16) {
+        HIP_TRY(hipSetDevice(ix->device));
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(ix->d_sample16);
+        ix->d_sample16 = nullptr; ix->sample16_cap = 0; ix->sample16_n = ix->sample16_S = 0;
+    }
+    return VDB_OK;
     });
 }
 

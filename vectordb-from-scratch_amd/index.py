@@ -295,6 +295,12 @@ class GpuFlatIndex(Index):
         if rc != 0:
             _raise(rc)
 
+    def set_sample_cache(self, on=True):
+        """The screening tier's compact bf16 copy of its sample rows (include/vdb_flat.h; on by default, results identical)."""
+        rc = self._L.vdb_flat_set_sample_cache(self._h, 1 if on else 0)
+        if rc != 0:
+            _raise(rc)
+
     def set_tiers(self, flags):
         """Test hook: force the hand-over of queries to the slower tiers (VDB_TIERS_*).  Results are identical."""
         rc = self._L.vdb_flat_set_tiers(self._h, int(flags))
@@ -317,6 +323,14 @@ class GpuFlatIndex(Index):
             _raise(rc)
         keys = ["eps_coef", "c_acc", "kappa", "nd_max", "ed_max", "rho_max", "lower_bound_scores", "ld"]
         return scores, qinfo, dict(zip(keys, consts.tolist()))
+
+    def debug_last_thresholds(self, nq):
+        """The screening tier's per-query filter thresholds of the last search (first nq queries)."""
+        out = np.zeros(int(nq), dtype=np.float32)
+        rc = self._L.vdb_flat_debug_last_thresholds(self._h, _fp(out), int(nq))
+        if rc:
+            _raise(rc)
+        return out
 
     def debug_row_info(self):
         """[rows, 4] f32: exact-order norm, alpha, beta, margin."""
