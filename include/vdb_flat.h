@@ -236,7 +236,8 @@ int vdb_flat_set_shadow(vdb_flat_index *h, int on);
 /*
  * The screening tier's SAMPLE CACHE (on by default; no reference counterpart; results identical either way).  The tier
  * derives its per-query filter thresholds from the scores of S <= 65536 sample rows spread over the index.  With the cache
- * the index keeps a compact bf16 copy of exactly those rows (S * padded dimension * 2 bytes: 100 MB beside a 3 GB index),
+ * the index keeps a compact bf16 copy of exactly those rows (S * padded dimension * 2 bytes: 100 MB beside a 3 GB index;
+ * S <= max(16384, rows / 8), so never more than an eighth of the f32 store),
  * rebuilt by the first search after rows were added, and the sample pass streams it instead of gathering the rows from
  * the f32 store: half the bytes, contiguous.  Same roundings, same MFMA order -> the same thresholds, bit for bit.
  * Used when the padded row length is a multiple of 64 elements.  on = 0 frees the copy and restores the f32 gather.
