@@ -3,7 +3,10 @@
 pre-filter masks, k and batch sizes through BOTH tier configurations of the engine, compared bit for bit with each other
 and (on a sample of queries) with the CPU oracle.  Any mismatch prints the failing configuration and exits non-zero.
 
-    python tools/fuzz_parity.py [--cases N] [--seed S] [--max-rows R]
+    python tools/fuzz_parity.py [--cases N] [--seed S] [--max-rows R] [--shadow]
+
+--shadow additionally runs every case with the opt-in bf16 shadow rows (vdb_flat_set_shadow) and with the sample cache off
+(vdb_flat_set_sample_cache(0)): same results, same tier counters.
 """
 import argparse
 import os
@@ -44,6 +47,7 @@ def main():
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-rows", type=int, default=300000)
+    ap.add_argument("--shadow", action="store_true")
     a = ap.parse_args()
     vdb = load_package()
     vdb.build()
@@ -98,6 +102,20 @@ def main():
         ix.set_screen(0)
         a0 = ix.search_batch_arrays(queries, k, **kw)
         ok = all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(a1, a0))
+        if a.shadow:
+            ctr = ("bf16_screen", "uncertified", "rethreshold_queries", "f32_tier_queries", "exact_queries", "pool_overflows")
+            ix.set_screen(1)
+            ix.set_shadow(True)
+            a2 = ix.search_batch_arrays(queries, k, **kw)
+            s2 = ix.last_stats()
+            ix.set_shadow(False)
+            ix.set_sample_cache(False)
+            a3 = ix.search_batch_arrays(queries, k, **kw)
+            s3 = ix.last_stats()
+            ix.set_sample_cache(True)
+            for ax, sx in ((a2, s2), (a3, s3)):
+                ok &= all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(a1, ax))
+                ok &= all(sx[c] == st[c] for c in ctr)
         for b in sorted({0, nq // 2, nq - 1}):
             oi, od = oracle.flat_search(metric, rows, queries[b], k, ids=ids, live=elig)
             gi, gd, gc = a1
