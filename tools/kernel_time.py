@@ -30,6 +30,6 @@ for _ in range(20):
 torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 50
 print("host us (enqueued, flags on host, total):", np.mean(hs, axis=0) / 1e3)
 ix.set_profile(True); ks = []
-for _ in range(10): step(); ks.append(ix.last_stats()["fused_kernel_ns"] / 1e6)
+for _ in range(int(os.environ.get("KT_ITERS", 10))): step(); ks.append(ix.last_stats()["fused_kernel_ns"] / 1e6)
 st = ix.last_stats()
-print(f"shadow_rows {st['shadow_rows']}  step {ms:.3f} ms  kernel {np.mean(ks):.4f} ms (min {min(ks):.4f})  {4.0*n*dim/np.mean(ks)/1e9:.2f} TB/s  uncert {st['uncertified']} f32q {st['f32_tier_queries']} ovf {st['pool_overflows']}")
+print(f"shadow_rows {st['shadow_rows']}  step {ms:.3f} ms  kernel {np.mean(ks):.4f} ms (median {np.median(ks):.4f}, min {min(ks):.4f})  {4.0*n*dim/np.mean(ks)/1e9:.2f} TB/s  uncert {st['uncertified']} f32q {st['f32_tier_queries']} ovf {st['pool_overflows']}")

@@ -1018,25 +1018,40 @@ __global__ __launch_bounds__(RR_THREADS) void rerank_kernel(RerankParams p) {
         if (processed == 0) { VDB_STAMP(2) }
         VDB_STAMP(5)
         processed = target;
-        // ---- sort the (dist, id) pairs re-ranked so far, ascending: rank by counting.  Every thread owns one pair and counts
-        // the pairs below it (ties -- only ineligible slots, all (max, ~0) -- broken by position), reading the list from LDS at
-        // one address per step for the whole wave; then the pairs move to their ranks.  Two barriers instead of the 21-36
-        // dependent compare-exchange steps of a bitonic network (2.8 us per round at 48 candidates).
-        {
-            uint32_t myd = 0xffffffffu, rank = 0;
-            uint64_t myi = ~0ull;
-            if (tid < processed) {
-                myd = sDist[tid]; myi = sId[tid];
-                for (uint32_t j = 0; j < processed; ++j) {
-                    const uint32_t dj = sDist[j];
-                    const uint64_t ij = sId[j];
-                    rank += (dj < myd || (dj == myd && (ij < myi || (ij == myi && j < tid)))) ? 1u : 0u;
-                }
-            }
-            __syncthreads();
-            if (tid < processed) { sDist[rank] = myd; sId[rank] = myi; }
-            __syncthreads();
+        // (ranking by counting -- what the gather-select now does for its short lists -- was tried here too: 3.8 us per round
+        // against 2.8 for this network at 48 pairs; the 96-bit (distance, id) compare costs more than the barrier-free steps save)
+        // ---- bitonic sort of the first P >= processed (dist, id) pairs, ascending; unused slots hold the maximum
+        uint32_t P = 32;
+        while (P < processed) P <<= 1;
+#define VDB_CEX()                                                                                      \
+        {                                                                                              \
+            uint32_t lo = 2 * tid - (tid & (stride - 1));                                              \
+            uint32_t hi = lo + stride;                                                                 \
+            bool up = ((lo & size) == 0);                                                              \
+            uint32_t da = sDist[lo], db = sDist[hi];                                                   \
+            uint64_t ia = sId[lo], ib = sId[hi];                                                       \
+            bool gt = da > db || (da == db && ia > ib);                                                \
+            if (gt == up) { sDist[lo] = db; sDist[hi] = da; sId[lo] = ib; sId[hi] = ia; }              \
         }
+        if (P <= 128) {
+            // at most 64 compare-exchange pairs: ONE wave does the whole network.  LDS operations of a wave execute in
+            // order, so the steps need no workgroup barrier between them -- only the compiler must keep their order.
+            if (wv == 0)
+                for (uint32_t size = 2; size <= P; size <<= 1)
+                    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                        if (tid < P / 2) VDB_CEX()
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+            __syncthreads();
+        } else {
+            for (uint32_t size = 2; size <= P; size <<= 1)
+                for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                    if (tid < P / 2) VDB_CEX()
+                    __syncthreads();
+                }
+        }
+#undef VDB_CEX
         if (processed <= p.kp_first) { VDB_STAMP(3) }
         // number of real candidates so far (ineligible ones sorted to the end with id ~0)
         if (tid < RR_MAX) {
