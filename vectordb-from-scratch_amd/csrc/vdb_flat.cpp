@@ -248,6 +248,7 @@ int grow(Index* ix, uint32_t need_rows) {
     if (ix->shadow) {
         HIP_TRY(hipMalloc((void**)&r16, (size_t)cap * ix->ld * 2));
         if (old && ix->d_rows16) HIP_TRY(hipMemcpyAsync(r16, ix->d_rows16, (size_t)old * ix->ld * 2, hipMemcpyDeviceToDevice, s));
+        else if (old) vdb::launch_rows_to_bf16(ix->d_rows, r16, ix->ld, 0, old, s);     // no shadow yet: from the f32 rows, never left unset
         HIP_TRY(hipMemsetAsync((char*)r16 + (size_t)old * ix->ld * 2, 0, (size_t)(cap - old) * ix->ld * 2, s));
     }
     if (old) {
@@ -721,13 +722,15 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
             const size_t need = (size_t)S * ld;
             if (ix->sample16_cap < need) {
                 if (ix->d_sample16) { HIP_TRY(hipDeviceSynchronize()); (void)hipFree(ix->d_sample16); ix->d_sample16 = nullptr; ix->sample16_cap = 0; }
-                HIP_TRY(hipMalloc((void**)&ix->d_sample16, need * 2));
-                ix->sample16_cap = need;
+                if (hipMalloc((void**)&ix->d_sample16, need * 2) == hipSuccess) ix->sample16_cap = need;
+                else { (void)hipGetLastError(); ix->d_sample16 = nullptr; sample_copy = false; }   // no memory for the optional copy: f32 gather
             }
-            vdb::launch_sample_to_bf16(ix->d_rows, ld, n, S, pl.shift, ix->d_sample16, s);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(s));                        // once per change of the rows: later searches on OTHER streams read it
-            ix->sample16_n = n; ix->sample16_S = S;
+            if (sample_copy) {
+                vdb::launch_sample_to_bf16(ix->d_rows, ld, n, S, pl.shift, ix->d_sample16, s);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(s));                    // once per change of the rows: later searches on OTHER streams read it
+                ix->sample16_n = n; ix->sample16_S = S;
+            }
         }
     }
     if (alt) {                                                   // the other stream starts behind query_prep and the row mask
@@ -2026,14 +2029,16 @@ int vdb_flat_set_shadow(vdb_flat_index* ix, int on) {
         ix->d_rows16 = nullptr; ix->shadow = false;
         return VDB_OK;
     }
-    ix->shadow = true;
     if (!ix->d_rows16 && ix->cap_rows) {
-        HIP_TRY(hipMalloc((void**)&ix->d_rows16, (size_t)ix->cap_rows * ix->ld * 2));
-        HIP_TRY(hipMemsetAsync(ix->d_rows16, 0, (size_t)ix->cap_rows * ix->ld * 2, ix->stream));
-        vdb::launch_rows_to_bf16(ix->d_rows, ix->d_rows16, ix->ld, 0, ix->n_uploaded, ix->stream);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(ix->stream));
+        uint16_t* r16 = nullptr;
+        HIP_TRY(hipMalloc((void**)&r16, (size_t)ix->cap_rows * ix->ld * 2));
+        hipError_t e = hipMemsetAsync(r16, 0, (size_t)ix->cap_rows * ix->ld * 2, ix->stream);
+        if (e == hipSuccess) { vdb::launch_rows_to_bf16(ix->d_rows, r16, ix->ld, 0, ix->n_uploaded, ix->stream); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+        if (e != hipSuccess) { (void)hipFree(r16); return fail(VDB_ERR_DEVICE, "building the bf16 shadow failed: %s", hipGetErrorString(e)); }
+        ix->d_rows16 = r16;                                       // only a COMPLETE shadow is ever visible to a search
     }
+    ix->shadow = true;
     return VDB_OK;
     });
 }
