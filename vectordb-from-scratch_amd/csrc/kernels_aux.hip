@@ -90,6 +90,10 @@ __device__ __forceinline__ float fold_sqdiff(const float* __restrict__ q, const 
 
 // The same folds over a SLICE of the pair, resumed from a partial sum: fold(q, x, d) == part(q + d1, x + d1, d - d1, part(q, x, d1, 0))
 // for any d1 that is a multiple of 16 (the same sequence of roundings, element by element) -- rerank_kernel's K slices.
+typedef float vdb_f2 __attribute__((ext_vector_type(2)));
+// (products and differences two at a time -- v_pk_mul_f32 / v_pk_add_f32, each lane of a packed op rounds exactly like the
+// scalar op -- the ADDS stay one by one, in order: the fold is the reference's.  One wave folds 48 candidates and is bound by
+// its own instruction stream, so fewer instructions per element is time.)
 __device__ __forceinline__ float fold_dot_part(const float* __restrict__ q, const float* __restrict__ x, uint32_t d, float s) {
     uint32_t i = 0;
     for (; i + 16 <= d; i += 16) {
@@ -101,10 +105,12 @@ __device__ __forceinline__ float fold_dot_part(const float* __restrict__ q, cons
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            s = __fadd_rn(s, __fmul_rn(a[u].x, b[u].x));
-            s = __fadd_rn(s, __fmul_rn(a[u].y, b[u].y));
-            s = __fadd_rn(s, __fmul_rn(a[u].z, b[u].z));
-            s = __fadd_rn(s, __fmul_rn(a[u].w, b[u].w));
+            const vdb_f2 p01 = vdb_f2{a[u].x, a[u].y} * vdb_f2{b[u].x, b[u].y};
+            const vdb_f2 p23 = vdb_f2{a[u].z, a[u].w} * vdb_f2{b[u].z, b[u].w};
+            s = __fadd_rn(s, p01.x);
+            s = __fadd_rn(s, p01.y);
+            s = __fadd_rn(s, p23.x);
+            s = __fadd_rn(s, p23.y);
         }
     }
     for (; i < d; ++i) s = __fadd_rn(s, __fmul_rn(q[i], x[i]));
@@ -121,11 +127,13 @@ __device__ __forceinline__ float fold_sqdiff_part(const float* __restrict__ q, c
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            float t;
-            t = __fsub_rn(a[u].x, b[u].x); s = __fadd_rn(s, __fmul_rn(t, t));
-            t = __fsub_rn(a[u].y, b[u].y); s = __fadd_rn(s, __fmul_rn(t, t));
-            t = __fsub_rn(a[u].z, b[u].z); s = __fadd_rn(s, __fmul_rn(t, t));
-            t = __fsub_rn(a[u].w, b[u].w); s = __fadd_rn(s, __fmul_rn(t, t));
+            const vdb_f2 t01 = vdb_f2{a[u].x, a[u].y} - vdb_f2{b[u].x, b[u].y};
+            const vdb_f2 t23 = vdb_f2{a[u].z, a[u].w} - vdb_f2{b[u].z, b[u].w};
+            const vdb_f2 p01 = t01 * t01, p23 = t23 * t23;
+            s = __fadd_rn(s, p01.x);
+            s = __fadd_rn(s, p01.y);
+            s = __fadd_rn(s, p23.x);
+            s = __fadd_rn(s, p23.y);
         }
     }
     for (; i < d; ++i) { float t = __fsub_rn(q[i], x[i]); s = __fadd_rn(s, __fmul_rn(t, t)); }
