@@ -53,6 +53,33 @@ def test_release_library_reads_no_environment():
                 assert any(stack), f"{f}:{ln}: getenv outside #ifdef VDB_DIAG"
 
 
+def test_shadow_row_kernel_keeps_its_hand_allocated_accumulators_to_itself():
+    """kernels_fused_s16.hip names its 256 accumulators a[0:255] by hand; hipcc does not know that and would use "free"
+    AccVGPRs as spill space under register pressure, silently overwriting accumulators (it did once, in the sample
+    instance).  The Makefile checks the generated code at every build; this runs the same check on the code the library
+    in the tree was built from, and checks that the checker still catches a planted violation."""
+    import subprocess
+    import sys
+    vdb = load_package()
+    vdb.build()
+    csrc = os.path.join(ROOT, "vectordb-from-scratch_amd", "csrc")
+    asm = os.path.join(csrc, "kernels_fused_s16.s")
+    if not os.path.exists(asm):                                           # an older build directory: regenerate
+        subprocess.run(["make", "-C", csrc, "-B", "kernels_fused_s16.o"], check=True, capture_output=True)
+    chk = os.path.join(csrc, "check_s16_asm.py")
+    r = subprocess.run([sys.executable, chk, asm], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    txt = open(asm).read()
+    bad = txt.replace("s_endpgm", "v_accvgpr_write_b32 a41, v1\n\ts_endpgm", 1)       # what the compiler once generated
+    tmp = os.path.join(csrc, "_planted.s")
+    try:
+        open(tmp, "w").write(bad)
+        r2 = subprocess.run([sys.executable, chk, tmp], capture_output=True, text=True)
+        assert r2.returncode != 0 and "AccVGPR" in r2.stderr
+    finally:
+        os.remove(tmp)
+
+
 def test_header_cites_reference_lines():
     header = open(os.path.join(ROOT, "include", "vdb_flat.h")).read()
     for cite in ["src/index.rs", "src/flat_index.rs", "src/storage.rs", "src/distance.rs", "src/error.rs"]:
