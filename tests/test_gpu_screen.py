@@ -353,3 +353,53 @@ def test_sample_cache_gives_the_same_thresholds_and_results(vdb):
         ids = np.arange(0, n0 + n1, 3)
         np.bitwise_or.at(mask, ids // 64, np.uint64(1) << (ids % 64).astype(np.uint64))
         both(id_mask=mask, mask_bits=n0 + n1)
+
+
+def test_nan_and_wild_norms_under_the_min_test_of_the_epilogue(vdb):
+    """The filter epilogues test the MINIMUM of four scores against the threshold when no score of the launch can be NaN
+    (every row and query norm within [2^-40, 2^40]: kernels.h fused_no_nan) and add a NaN test per group otherwise.  A NaN row
+    must still reach the exact re-rank (the reference panics on a NaN distance, flat_index.rs:62 -> VDB_ERR_NAN), and rows /
+    queries outside the tame domain must not change a result."""
+    rng = np.random.default_rng(77)
+    n, d, nq, k = 70_000, 64, 24, 10
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    for metric in (0, 1, 2):
+        # (a) a NaN element somewhere in the index: every search fails with the NaN error.  An inf element gives inf (Euclid, Dot:
+        # the reference sorts it without complaint) or NaN (Cosine) distances: whatever the f32 tier does, the screening tier does
+        for bad in (float("nan"), float("inf")):
+            rows = base.copy()
+            rows[12345, 3] = bad
+            ix = make_index(vdb, metric, rows)
+            outcome = []
+            for screen in (1, 0):
+                ix.set_screen(screen)
+                try:
+                    outcome.append(ix.search_batch_arrays(q, k))
+                except vdb.VectorDbError as e:
+                    outcome.append(str(e))
+                assert ix.last_stats()["bf16_screen"] == screen
+            ix.set_screen(1)
+            if bad != bad or metric == 1:
+                assert isinstance(outcome[0], str) and "NaN" in outcome[0] and outcome[0] == outcome[1], outcome
+            else:
+                assert not isinstance(outcome[0], str) and same(outcome[0], outcome[1])
+                check_oracle(metric, rows, q, k, outcome[0], [0, nq - 1])
+        # (b) a row and (c) a query far outside the tame domain, (d) rows with tiny norms: results equal the f32 tier's and the oracle's
+        rows = base.copy()
+        rows[777] *= np.float32(1e25)
+        rows[778] *= np.float32(1e-22)
+        ix = make_index(vdb, metric, rows)
+        a, st, b = both_tiers(ix, q, k)
+        assert st["bf16_screen"] == 1 and same(a, b)
+        check_oracle(metric, rows, q, k, a, [0, nq - 1])
+        q2 = q.copy()
+        q2[5] *= np.float32(1e18)
+        ix2 = make_index(vdb, metric, base)
+        a2, st2, b2 = both_tiers(ix2, q2, k)
+        assert st2["bf16_screen"] == 1 and same(a2, b2)
+        check_oracle(metric, base, q2, k, a2, [5, 6])
+        # and the next, tame search on the same handle is not stuck with the wild query's norm
+        a3, st3, b3 = both_tiers(ix2, q, k)
+        assert same(a3, b3)
+        check_oracle(metric, base, q, k, a3, [0])

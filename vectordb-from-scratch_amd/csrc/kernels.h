@@ -125,7 +125,7 @@ struct SelectParams {
     // gather mode (n_sub > 0): the query's keys live in n_sub sub-pools of capacity capl,
     // keys[(q*n_sub + s)*capl + j], j < sub_counts[q*n_sub + s]
     const uint32_t* sub_counts; uint32_t n_sub; uint32_t capl;
-    uint32_t wg_major;                                 // 1: the keys of sub-pool i = wg*4 + r of query q are at ((wg*256 + q)*4 + r)*capl (bf16 tier)
+    uint32_t wg_major;                                 // 1: sub-pool i = wg*4 + r of query q has its count at (wg*256 + q)*4 + r and its keys at that * capl (bf16 tier)
     uint32_t kk;                                       // how many smallest keys to keep (<= 2048)
     uint64_t* out_keys; uint32_t out_stride;           // sorted ascending, padded with EMPTY_KEY
     uint32_t* out_cnt;
@@ -181,8 +181,11 @@ struct FusedBf16Params {
     // contribute for THIS row and query -- the certificate then needs no per-index maxima (kernels_aux.hip cert_test)
     const float* margin; const float* qg;
     const uint32_t* rowmask;                           // NEVER null: the live mask when there is no filter
+    // "No score of this launch can be NaN" (fused_no_nan below): the index scalars (max |d|^2, smallest positive |d|^2 under
+    // Cosine) and the largest query norm of the search as f32 bits (query_prep: status block word 2).  May be null (= unknown).
+    const uint32_t* scalars; const uint32_t* qmax_bits;
     // filter mode: keys with score <= thr[q] go to the private sub-pool
-    //   sub = ((q*n_wg + range)*2 + row half)*2 + lane half ; keys at pool[sub*capl ..], count at pool_cnt[sub]
+    //   sub = ((wg*256 + q)*2 + row half)*2 + lane half ; keys at pool[sub*capl ..], count at pool_cnt[sub]  (workgroup-major)
     const float* thr;                                  // [256]
     uint64_t* pool; uint32_t* pool_cnt; uint32_t capl;
     uint32_t n_wg;                                     // row ranges = grid.x
@@ -196,6 +199,17 @@ void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s);      // unpipel
 #endif
 void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s);
 void launch_fused_bf16p(const FusedBf16Params& p, hipStream_t s);     // kernels_fused_bf16p.hip: the filter pass, software-pipelined (default)
+// With every row norm and query norm in [2^-40, 2^40] (zero allowed) no accumulator can overflow and no alpha / beta is
+// non-finite, so fma(acc, alpha, beta) is never NaN -- the filter epilogues may then test the MINIMUM of four scores against the
+// threshold (v_min_f32 drops a NaN operand; a NaN score must pass the filter, flat_index.rs:62).  Otherwise they add a NaN
+// test per group.  Wave-uniform, evaluated once per launch.
+__device__ inline bool fused_no_nan(const uint32_t* scalars, const uint32_t* qmax_bits, bool cosine) {
+    if (!scalars || !qmax_bits) return false;
+    const uint32_t n2max = scalars[0], qmax = *qmax_bits;
+    bool ok = n2max <= 0x67800000u /* 2^80 */ && qmax <= 0x53800000u /* 2^40 */;
+    if (cosine) { const uint32_t mb = scalars[5]; ok = ok && mb != 0u && (~mb) >= 0x17800000u /* 2^-80 */; }
+    return ok;
+}
 void launch_fused_s16(const FusedBf16Params& p, hipStream_t s);       // kernels_fused_s16.hip: the filter pass over p.rows16 (ld % 64 == 0)
 void launch_sample_s16(const FusedBf16Params& p, hipStream_t s);      // the sample pass over a COMPACT bf16 copy of the sample rows (p.rows16 = the copy)
 uint32_t fused_bf16_tile_rows();

@@ -369,6 +369,7 @@ __global__ __launch_bounds__(256) void query_prep_kernel(QueryPrepParams p) {
         if (q < p.nq) {
             n = __builtin_sqrtf(fold_sq(sQrow, p.dim));                // sequential fold, from LDS
             if (p.metric == COSINE && n == 0.0f) atomicOr(p.status, ST_ZERO_QUERY);
+            if (p.qb) atomicMax(p.status + 2, __float_as_uint(n));   // largest query norm of the search (NaN bits > inf bits > finite): fused_no_nan
         }
         p.qnorm[q] = n;
         if (p.qb && p.qg) {
@@ -497,7 +498,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
         bool over = false;
         for (uint32_t i0 = 0; i0 < p.n_sub; i0 += SEL_THREADS) {
             const uint32_t i = i0 + tid;
-            uint32_t c = i < p.n_sub ? sc[i] : 0u;
+            // (bf16 tier: counts workgroup-major like the keys -- four consecutive threads read one workgroup's 16 bytes)
+            uint32_t c = i < p.n_sub ? (p.wg_major ? p.sub_counts[((size_t)(i >> 2) * 256u + q) * 4u + (i & 3u)] : sc[i]) : 0u;
             if (c > p.capl) { c = p.capl; over = true; }
             uint32_t incl = c;
             for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o); if ((int)lane >= o) incl += t; }
@@ -898,7 +900,7 @@ __device__ __forceinline__ float score_cut(const RerankParams& p, uint32_t q, do
 __global__ __launch_bounds__(256) void pool_to_dense_kernel(const uint64_t* pool, const uint32_t* pool_cnt, uint32_t n_sub,
                                                             uint32_t capl, uint32_t n_rows, float* dense) {
     const uint32_t q = blockIdx.y, i = blockIdx.x;                 // sub-pool i = wg*4 + r of query q
-    uint32_t c = pool_cnt[(size_t)q * n_sub + i];
+    uint32_t c = pool_cnt[((size_t)(i >> 2) * 256u + q) * 4u + (i & 3u)];
     if (c > capl) c = capl;
     const uint64_t* src = pool + (((size_t)(i >> 2) * 256u + q) * 4u + (i & 3u)) * capl;
     for (uint32_t j = threadIdx.x; j < c; j += blockDim.x) {

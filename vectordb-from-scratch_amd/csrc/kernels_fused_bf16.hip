@@ -117,12 +117,12 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16_kernel(FusedBf16Params p) {
     size_t sub_a = 0, sub_b = 0;
     float thr_a = 0.f, thr_b = 0.f;
     if (!SAMPLE) {
-        sub_a = (((size_t)q_a * p.n_wg + blockIdx.x) * 2 + wr) * 2 + h;
-        sub_b = (((size_t)q_b * p.n_wg + blockIdx.x) * 2 + wr) * 2 + h;
+        sub_a = (((size_t)blockIdx.x * TQ + q_a) * 2 + wr) * 2 + h;          // counts workgroup-major too (kernels_fused_bf16p.hip)
+        sub_b = (((size_t)blockIdx.x * TQ + q_b) * 2 + wr) * 2 + h;
         // The pool KEYS are laid out workgroup-major -- slot ((wg*256 + q)*4 + row half*2 + lane half)*capl -- so that the
         // few scattered appends of one workgroup fall into ONE 2 MB region instead of one region per query (256 regions
-        // 2 MB apart: every append then missed the CU's address-translation cache in front of the row stream).  The
-        // counts stay query-major (pool_cnt[sub]); the select's gather knows both layouts (SelectParams::wg_major).
+        // 2 MB apart: every append then missed the CU's address-translation cache in front of the row stream); the
+        // select's gather knows both layouts (SelectParams::wg_major).
         pool_a = p.pool + ((((size_t)blockIdx.x * TQ + q_a) * 2 + wr) * 2 + h) * p.capl;
         pool_b = p.pool + ((((size_t)blockIdx.x * TQ + q_b) * 2 + wr) * 2 + h) * p.capl;
         thr_a = p.thr[q_a];

@@ -103,12 +103,14 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
     size_t sub_a = 0, sub_b = 0;
     float thr_a = 0.f, thr_b = 0.f;
     if (!SAMPLE) {
-        sub_a = (((size_t)q_a * p.n_wg + blockIdx.x) * 2 + wr) * 2 + h;
-        sub_b = (((size_t)q_b * p.n_wg + blockIdx.x) * 2 + wr) * 2 + h;
+        // the COUNTS are workgroup-major as well (since the end of round 2): the 1024 counts of a workgroup are one 4 KB block
+        // written in whole lines, not 1024 four-byte stores 4 KB apart (262 000 scattered stores per launch, ~10 us of tail)
+        sub_a = (((size_t)blockIdx.x * TQ + q_a) * 2 + wr) * 2 + h;
+        sub_b = (((size_t)blockIdx.x * TQ + q_b) * 2 + wr) * 2 + h;
         // The pool KEYS are laid out workgroup-major -- slot ((wg*256 + q)*4 + row half*2 + lane half)*capl -- so that the
         // few scattered appends of one workgroup fall into ONE 2 MB region instead of one region per query (256 regions
         // 2 MB apart: every append then missed the CU's address-translation cache in front of the row stream).  The
-        // counts stay query-major (pool_cnt[sub]); the select's gather knows both layouts (SelectParams::wg_major).
+        // select's gather knows both layouts (SelectParams::wg_major).
         pool_a = p.pool + ((((size_t)blockIdx.x * TQ + q_a) * 2 + wr) * 2 + h) * p.capl;
         pool_b = p.pool + ((((size_t)blockIdx.x * TQ + q_b) * 2 + wr) * 2 + h) * p.capl;
         thr_a = p.thr[q_a];
@@ -119,6 +121,8 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
         asm volatile("" : "+v"(thr_a), "+v"(thr_b));
     }
     uint32_t pcnt_a = 0, pcnt_b = 0;
+    // can a score of this launch be NaN at all?  (wave-uniform; decides how the epilogue tests four scores at once)
+    const bool no_nan = !SAMPLE && fused_no_nan(p.scalars, p.qmax_bits, !MARGIN);
     if (ntiles == 0) {
         if (!SAMPLE) { p.pool_cnt[sub_a] = 0; p.pool_cnt[sub_b] = 0; }
         return;
@@ -424,10 +428,24 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
                         // Hits are rare (about 0.2 % of the elements).  Common path per query: four compares whose
                         // lane masks are OR-ed on the scalar unit and ONE not-taken branch; the append code is out of
                         // line.  `!(s > thr)` keeps a NaN score (it must reach the re-rank, flat_index.rs:62).
-                        const unsigned long long ma = __builtin_amdgcn_ballot_w64(!(sa0 > thp_a)) | __builtin_amdgcn_ballot_w64(!(sa1 > thp_a)) |
-                                                      __builtin_amdgcn_ballot_w64(!(sa2 > thp_a)) | __builtin_amdgcn_ballot_w64(!(sa3 > thp_a));
-                        const unsigned long long mb = __builtin_amdgcn_ballot_w64(!(sb0 > thp_b)) | __builtin_amdgcn_ballot_w64(!(sb1 > thp_b)) |
-                                                      __builtin_amdgcn_ballot_w64(!(sb2 > thp_b)) | __builtin_amdgcn_ballot_w64(!(sb3 > thp_b));
+                        // ONE compare per query for the four rows: the smallest of the four scores against the threshold.
+                        // v_min_f32 drops a NaN operand and a NaN score must pass (flat_index.rs:62) -- so this form is used
+                        // as it stands only when no score of the launch can be NaN (fused_no_nan: every norm within
+                        // [2^-40, 2^40]); otherwise a NaN-propagating sum of the four is tested as well (inf - inf gives a
+                        // false alarm, which the exact per-row test of the rare path sorts out).
+                        const f32x2 na_ = __builtin_elementwise_min(ra01, ra23), nb_ = __builtin_elementwise_min(rb01, rb23);
+                        bool hit_a = !(fminf(na_.x, na_.y) > thp_a), hit_b = !(fminf(nb_.x, nb_.y) > thp_b);
+                        if (!no_nan) {
+                            const f32x2 ua_ = ra01 + ra23, ub_ = rb01 + rb23;
+                            const float ta_ = ua_.x + ua_.y, tb_ = ub_.x + ub_.y;
+                            hit_a = hit_a || (ta_ != ta_);
+                            hit_b = hit_b || (tb_ != tb_);
+                        }
+                        if (kDiag && (p.ablate & 4096u)) {                  // diag 4096: round 1's four compares per query (A/B)
+                            hit_a = !(sa0 > thp_a) || !(sa1 > thp_a) || !(sa2 > thp_a) || !(sa3 > thp_a);
+                            hit_b = !(sb0 > thp_b) || !(sb1 > thp_b) || !(sb2 > thp_b) || !(sb3 > thp_b);
+                        }
+                        const unsigned long long ma = __builtin_amdgcn_ballot_w64(hit_a), mb = __builtin_amdgcn_ballot_w64(hit_b);
                         // The append path is what the epilogue costs (with thresholds that let nothing pass the kernel is as
                         // fast as without an epilogue), so it is kept short: one 4-bit hit mask per lane and query, then a
                         // loop over its set bits -- typically one lane, one iteration -- instead of four masked regions.
@@ -491,7 +509,7 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
     if (st < total) { run_stage(st, B2{}, std::false_type{}); ++st; }
     if (st < total) { run_stage(st, B0{}, std::false_type{}); ++st; }
     if (st < total) { run_stage(st, B1{}, std::false_type{}); ++st; }
-    if (!SAMPLE) {
+    if (!SAMPLE && !(kDiag && (p.ablate & 2048u))) {                    // diag 2048: the counts are not written (cost of these stores)
         p.pool_cnt[sub_a] = pcnt_a;
         p.pool_cnt[sub_b] = pcnt_b;
     }

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         q_of[j] = wq * 128 + 32 * j + c;
         sub[j] = 0; pool[j] = nullptr; thr[j] = 0.f; pcnt[j] = 0;
         if (SAMPLE) continue;
-        sub[j] = (((size_t)q_of[j] * p.n_wg + blockIdx.x) * 2 + wr) * 2 + h;
+        sub[j] = (((size_t)blockIdx.x * TQ + q_of[j]) * 2 + wr) * 2 + h;      // counts workgroup-major, like the keys
         pool[j] = p.pool + ((((size_t)blockIdx.x * TQ + q_of[j]) * 2 + wr) * 2 + h) * p.capl;
         thr[j] = p.thr[q_of[j]];
         if (kDiag && (p.ablate & 16u)) thr[j] = -__builtin_inff();
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         return;
     }
     if (SAMPLE && r0 >= r1) return;
+    const bool no_nan = !SAMPLE && fused_no_nan(p.scalars, p.qmax_bits, !MARGIN);     // wave-uniform: can a score of this launch be NaN?
     const uint32_t NS = ntiles * (KH / 2);                              // row stages (= pairs of half-stages) of this workgroup
     const uint32_t last_row = p.n_rows - 1;
     const char* __restrict__ rows_b = reinterpret_cast<const char*>(p.rows16);
@@ -360,8 +361,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                                                    /* queries to the end of the epilogue and keeps 192 scores alive (spills) */ \
         } else {                                                                                       \
         const float tp = thp[J];                                                                       \
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(!(s0 > tp)) | __builtin_amdgcn_ballot_w64(!(s1 > tp)) | \
-                                     __builtin_amdgcn_ballot_w64(!(s2 > tp)) | __builtin_amdgcn_ballot_w64(!(s3 > tp));  \
+        /* ONE compare for the four rows: their smallest score against the threshold; where a score of the launch could */ \
+        /* be NaN (fused_no_nan says no) a NaN-propagating sum is tested as well (kernels_fused_bf16p.hip) */ \
+        const f32x2 mn_ = __builtin_elementwise_min(s01, s23);                                         \
+        bool hit_ = !(fminf(mn_.x, mn_.y) > tp);                                                       \
+        if (!no_nan) { const f32x2 u_ = s01 + s23; const float t_ = u_.x + u_.y; hit_ = hit_ || (t_ != t_); } \
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit_);                                \
         if (__builtin_expect(m != 0ull, 0)) {                                                          \
             uint32_t hm = (!(s0 > tp) ? 1u : 0u) | (!(s1 > tp) ? 2u : 0u) | (!(s2 > tp) ? 4u : 0u) | (!(s3 > tp) ? 8u : 0u); \
             hm &= (vbits >> (8 * (G4))) & 0xfu;                                                        \

@@ -754,6 +754,7 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
         fp.margin = ix->d_margin; fp.qg = ix->d_margin ? ix->cur->w_qg.p + q0 : nullptr;
         fp.thr = ix->cur->w_thr.p + q0; fp.pool = W->w_pool.p; fp.pool_cnt = W->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
+        fp.scalars = ix->d_scalars; fp.qmax_bits = d_status + 2;
         fp.ablate = ix->kn.bf16_ablate;
         fp.n_sample = S; fp.sample_shift = pl.shift;
         fp.sample_block = ix->kn.sample_block ? (n / (S / 256u)) : 0u; fp.minkeys = W->w_dense.p; fp.minkey_stride = M;
@@ -778,6 +779,13 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
             HIP_TRY(hipEventElapsedTime(&ms, ix->ev0, ix->ev1));
             ix->cur->stats[7] += (uint64_t)((double)ms * 1e6);
         }
+#ifdef VDB_DIAG
+        // An ablated launch leaves wrong pools behind; if the step went on with them every query would fall through to the
+        // slower tiers, and the extra milliseconds of f32 MFMA work change the clock the NEXT timed launch runs at (ablation
+        // arms with broken results read 10-25 us low for that reason alone).  So the ablated launch is the timed one, and an
+        // unablated launch (untimed) overwrites its pools: every arm of an A/B then runs the same step around the kernel.
+        if (fp.ablate) { fp.ablate = 0; launch_filter_pass(ix, fp, s); ix->cur->stats[3] += n; }
+#endif
         ix->cur->stats[3] += n;
 
         vdb::SelectParams mp{};
@@ -884,6 +892,7 @@ int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
         fp.margin = ix->d_margin; fp.qg = ix->d_margin ? ix->cur->w2_qg.p + q0 : nullptr;
         fp.thr = ix->cur->w2_thr.p + q0; fp.pool = ix->cur->w_pool.p; fp.pool_cnt = ix->cur->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
+        fp.scalars = ix->d_scalars; fp.qmax_bits = d_status + 2;
         launch_filter_pass(ix, fp, s);
         ix->cur->stats[3] += n;
         vdb::SelectParams mp{};
@@ -1213,7 +1222,9 @@ int search_part2(Index* ix, int* changed) {
         HIP_TRY(hipStreamSynchronize(s));
         st2 |= ix->cur->h_flags[0];
     }
-    ix->cur->status_dirty = st2 != 0 || ix->cur->stats[6] != 0 || ix->cur->stats[2] != 0;      // status bits, or the summary word was set
+    // status bits, the summary word, or a query norm beyond the kernels' no-NaN domain (word 2 is a running maximum: tame
+    // values may stay, a wild one must not outlive its search)
+    ix->cur->status_dirty = st2 != 0 || ix->cur->stats[6] != 0 || ix->cur->stats[2] != 0 || ix->cur->h_flags[2] > 0x53800000u;
     if (st2 & vdb::ST_NAN)
         return fail(VDB_ERR_NAN, "NaN distance (the reference panics here, flat_index.rs:62)");
     return VDB_OK;
@@ -1908,6 +1919,7 @@ int vdb_flat_debug_screen_scores(vdb_flat_index* ix, const float* queries, size_
     fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->cur->w_qb.p; fp.alpha = ix->d_alpha; fp.beta = ix->d_beta;
     fp.margin = lb ? ix->d_margin : nullptr; fp.qg = lb ? ix->cur->w_qg.p : nullptr;
     fp.rowmask = ix->d_live; fp.thr = ix->cur->w_thr.p; fp.pool = ix->cur->w_pool.p; fp.pool_cnt = ix->cur->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
+    fp.scalars = ix->d_scalars; fp.qmax_bits = ix->cur->w_flags.p + 2;
     launch_filter_pass(ix, fp, s);                                                // the PRODUCTION filter pass (shadow rows if enabled)
     vdb::launch_pool_to_dense(ix->cur->w_pool.p, ix->cur->w_subcnt.p, n_sub, capl, (uint32_t)nq, n, ix->cur->w_dbg.p, s);
     HIP_TRY(hipGetLastError());
