@@ -519,8 +519,18 @@ Bf16Plan plan_bf16(const vdb_flat_index* ix, uint32_t n, size_t k) {
     while (S > n) S /= 2;
     // threshold rank: enough for the first re-rank round; the pool (about N/S * kt keys) feeds the deeper rounds
     uint32_t kt = std::min<uint32_t>(want_kt, (uint32_t)(S / 256u));
+    // ... and no deeper than that: one sample rank stands for n / S rows, so rank kt lets about kt * n / S keys through.  Aim at
+    // ~6 k keys per query (k = 100 at 1.25M rows: rank 32 -> ~610 keys instead of rank 112 -> ~2100, of which the select kept
+    // 512 anyway).  Below rank k + 1 the sample no longer GUARANTEES k candidates; it does not have to -- the re-rank refuses
+    // to certify a result with fewer than k real rows and the query goes to the re-threshold pass (never observed: the pool
+    // size varies by about +-18 % at rank 32).
+    {
+        const uint64_t per_rank = std::max<uint64_t>(1, (uint64_t)n / S);
+        const uint32_t kt_pool = round_up((uint32_t)std::max<uint64_t>(16, (6ull * k + per_rank - 1) / per_rank), 16u);
+        kt = std::min(kt, kt_pool);
+    }
     if (ix->kn.kt16) kt = std::min<uint32_t>(ix->kn.kt16, (uint32_t)(S / 256u));
-    if (kt < k + 1 || kt < 16) return pl;
+    if (kt < 16) return pl;
     pl.kp = k > 48 ? 512 : 256;                                  // candidates the select delivers (depth limit of the re-rank)
     pl.S = (uint32_t)S; pl.kt = kt;
     while ((1ull << pl.shift) < S) ++pl.shift;
