@@ -487,3 +487,43 @@ def test_two_searches_in_flight_submit_wait(vdb):
     assert all(torch.equal(a, b) for a, b in zip(outs[3], ref[3]))
     ix.add(10**7, vdb.Vector(rows[0]))                          # mutations work again
     assert ix.len() == n + 1
+
+
+def test_sample_cache_with_two_searches_of_different_sample_size_in_flight(vdb):
+    """The compact bf16 copy of the sample rows is keyed by (rows uploaded, sample size).  Two searches in flight whose plans
+    differ in sample size (k = 10 and k = 100 on a 100k-row index: 16384 and 32768 sample rows) cannot both use it: the second
+    one finds the other workspace busy and keeps the f32 gather for its sample pass.  Results are the synchronous ones either
+    way, in both submission orders, and the copy is rebuilt for whoever comes next."""
+    import torch
+    rng = np.random.default_rng(123)
+    n, d, B = 100_000, 128, 64
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    ix = make_index(vdb, 1, rows)
+    q = torch.from_numpy(rng.standard_normal((B, d)).astype(np.float32)).to(dev)
+
+    def bufs(k):
+        return (torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+                torch.empty((B,), dtype=torch.int32, device=dev))
+
+    ref = {}
+    for k in (10, 100):
+        o = bufs(k)
+        ix.search_batch_device(q.data_ptr(), B, d, k, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr())
+        torch.cuda.synchronize()
+        ref[k] = tuple(t.clone() for t in o)
+        assert ix.last_stats()["bf16_screen"] == 1
+    assert ix.last_stats()["sample_rows"] == 32768                  # k = 100 doubled the sample
+    for order in ((10, 100), (100, 10), (10, 100)):
+        outs = {k: bufs(k) for k in order}
+        tickets = [ix.search_batch_device_submit(q.data_ptr(), B, d, k, outs[k][0].data_ptr(), outs[k][1].data_ptr(), outs[k][2].data_ptr())
+                   for k in order]
+        for t in tickets:
+            ix.search_batch_device_wait(t)
+        torch.cuda.synchronize()
+        for k in order:
+            assert all(torch.equal(a, b) for a, b in zip(outs[k], ref[k])), (order, k)
+    qh = q.cpu().numpy()
+    gi, gd, gc = ix.search_batch_arrays(qh, 10)
+    oi, od = oracle.flat_search(1, rows, qh[3], 10)
+    assert np.array_equal(gi[3], oi) and np.array_equal(gd[3].view(np.uint32), od.view(np.uint32))
