@@ -425,27 +425,26 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16p_kernel(FusedBf16Params p) {
                         VDB_MIN(0, sa0, sb0) VDB_MIN(1, sa1, sb1) VDB_MIN(2, sa2, sb2) VDB_MIN(3, sa3, sb3)
 #undef VDB_MIN
                     } else {
-                        // Hits are rare (about 0.2 % of the elements).  Common path per query: four compares whose
-                        // lane masks are OR-ed on the scalar unit and ONE not-taken branch; the append code is out of
-                        // line.  `!(s > thr)` keeps a NaN score (it must reach the re-rank, flat_index.rs:62).
-                        // ONE compare per query for the four rows: the smallest of the four scores against the threshold.
-                        // v_min_f32 drops a NaN operand and a NaN score must pass (flat_index.rs:62) -- so this form is used
+                        // Hits are rare (about 0.1 % of the elements).  ONE compare per query for the four rows: the smallest of the four
+                        // scores against the threshold, its lane mask straight into the not-taken branch; the append code is out of
+                        // line.  v_min_f32 drops a NaN operand and a NaN score must pass (flat_index.rs:62) -- so this form is used
                         // as it stands only when no score of the launch can be NaN (fused_no_nan: every norm within
                         // [2^-40, 2^40]); otherwise a NaN-propagating sum of the four is tested as well (inf - inf gives a
                         // false alarm, which the exact per-row test of the rare path sorts out).
                         const f32x2 na_ = __builtin_elementwise_min(ra01, ra23), nb_ = __builtin_elementwise_min(rb01, rb23);
-                        bool hit_a = !(fminf(na_.x, na_.y) > thp_a), hit_b = !(fminf(nb_.x, nb_.y) > thp_b);
-                        if (!no_nan) {
+                        unsigned long long ma = __builtin_amdgcn_ballot_w64(!(fminf(na_.x, na_.y) > thp_a));
+                        unsigned long long mb = __builtin_amdgcn_ballot_w64(!(fminf(nb_.x, nb_.y) > thp_b));
+                        if (__builtin_expect(!no_nan, 0)) {                  // a real (wave-uniform) branch: the empty asm keeps hipcc from
+                            asm volatile("" ::: "memory");                   // computing the sums always and selecting with v_cndmask
                             const f32x2 ua_ = ra01 + ra23, ub_ = rb01 + rb23;
                             const float ta_ = ua_.x + ua_.y, tb_ = ub_.x + ub_.y;
-                            hit_a = hit_a || (ta_ != ta_);
-                            hit_b = hit_b || (tb_ != tb_);
+                            ma |= __builtin_amdgcn_ballot_w64(ta_ != ta_);
+                            mb |= __builtin_amdgcn_ballot_w64(tb_ != tb_);
                         }
                         if (kDiag && (p.ablate & 4096u)) {                  // diag 4096: round 1's four compares per query (A/B)
-                            hit_a = !(sa0 > thp_a) || !(sa1 > thp_a) || !(sa2 > thp_a) || !(sa3 > thp_a);
-                            hit_b = !(sb0 > thp_b) || !(sb1 > thp_b) || !(sb2 > thp_b) || !(sb3 > thp_b);
+                            ma = __builtin_amdgcn_ballot_w64(!(sa0 > thp_a) || !(sa1 > thp_a) || !(sa2 > thp_a) || !(sa3 > thp_a));
+                            mb = __builtin_amdgcn_ballot_w64(!(sb0 > thp_b) || !(sb1 > thp_b) || !(sb2 > thp_b) || !(sb3 > thp_b));
                         }
-                        const unsigned long long ma = __builtin_amdgcn_ballot_w64(hit_a), mb = __builtin_amdgcn_ballot_w64(hit_b);
                         // The append path is what the epilogue costs (with thresholds that let nothing pass the kernel is as
                         // fast as without an epilogue), so it is kept short: one 4-bit hit mask per lane and query, then a
                         // loop over its set bits -- typically one lane, one iteration -- instead of four masked regions.

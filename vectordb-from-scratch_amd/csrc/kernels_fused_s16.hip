@@ -345,11 +345,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
             for (int j = 0; j < QT; ++j) best[j] = __uint_as_float(0x7f800000u);
             asm volatile("s_nop 7" ::: "memory");                       // the last MFMA of the k-step wrote a[240:255]; they are read last
-#define VDB_EPI_J(I, G4, J)                                                                            \
+#define VDB_EPI_J(I, G4, J, NN)                                                                        \
     {                                                                                                  \
-        float p0_, p1_, p2_, p3_;                                                                      \
-        VDB_ACC_READ(p0_, I, J, 4 * (G4) + 0); VDB_ACC_READ(p1_, I, J, 4 * (G4) + 1);                  \
-        VDB_ACC_READ(p2_, I, J, 4 * (G4) + 2); VDB_ACC_READ(p3_, I, J, 4 * (G4) + 3);                  \
+        float p0_, p1_, p2_, p3_;                              /* four reads in ONE asm: hipcc puts an s_nop behind every inline asm */ \
+        asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]" \
+                     : "=v"(p0_), "=v"(p1_), "=v"(p2_), "=v"(p3_)                                      \
+                     : "n"(16 * (4 * (I) + (J)) + 4 * (G4)), "n"(16 * (4 * (I) + (J)) + 4 * (G4) + 1), \
+                       "n"(16 * (4 * (I) + (J)) + 4 * (G4) + 2), "n"(16 * (4 * (I) + (J)) + 4 * (G4) + 3) : VDB_ALL_AGPRS); \
         const f32x2 p01 = {p0_, p1_}, p23 = {p2_, p3_};                                                \
         const f32x2 s01 = __builtin_elementwise_fma(p01, al01, be01), s23 = __builtin_elementwise_fma(p23, al23, be23); \
         const float s0 = s01.x, s1 = s01.y, s2 = s23.x, s3 = s23.y;                                    \
@@ -364,9 +366,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         /* ONE compare for the four rows: their smallest score against the threshold; where a score of the launch could */ \
         /* be NaN (fused_no_nan says no) a NaN-propagating sum is tested as well (kernels_fused_bf16p.hip) */ \
         const f32x2 mn_ = __builtin_elementwise_min(s01, s23);                                         \
-        bool hit_ = !(fminf(mn_.x, mn_.y) > tp);                                                       \
-        if (!no_nan) { const f32x2 u_ = s01 + s23; const float t_ = u_.x + u_.y; hit_ = hit_ || (t_ != t_); } \
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit_);                                \
+        unsigned long long m = __builtin_amdgcn_ballot_w64(!(fminf(mn_.x, mn_.y) > tp));                \
+        if (!(NN)) {                                           /* NN: compile-time copy of no_nan (the epilogue exists twice) */ \
+            const f32x2 u_ = s01 + s23; const float t_ = u_.x + u_.y;                                  \
+            m |= __builtin_amdgcn_ballot_w64(t_ != t_);                                                \
+        }                                                                                              \
         if (__builtin_expect(m != 0ull, 0)) {                                                          \
             uint32_t hm = (!(s0 > tp) ? 1u : 0u) | (!(s1 > tp) ? 2u : 0u) | (!(s2 > tp) ? 4u : 0u) | (!(s3 > tp) ? 8u : 0u); \
             hm &= (vbits >> (8 * (G4))) & 0xfu;                                                        \
@@ -384,22 +388,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }                                                                                              \
         }                                                                                              \
     }
-#define VDB_EPI_G(I, G4)                                                                               \
+#define VDB_EPI_G(I, G4, NN)                                                                           \
     {                                                                                                  \
         const float4 a4 = *reinterpret_cast<const float4*>(al + (I) * 32 + 8 * (G4));                  \
         const float4 b4 = *reinterpret_cast<const float4*>(be + (I) * 32 + 8 * (G4));                  \
         const f32x2 al01 = {a4.x, a4.y}, al23 = {a4.z, a4.w}, be01 = {b4.x, b4.y}, be23 = {b4.z, b4.w}; \
         const uint32_t rt0 = rowt + 8 * (G4);                                                          \
-        VDB_EPI_J(I, G4, 0) __builtin_amdgcn_sched_barrier(0); VDB_EPI_J(I, G4, 1) __builtin_amdgcn_sched_barrier(0);            \
-        VDB_EPI_J(I, G4, 2) __builtin_amdgcn_sched_barrier(0); VDB_EPI_J(I, G4, 3) __builtin_amdgcn_sched_barrier(0);            \
+        VDB_EPI_J(I, G4, 0, NN) __builtin_amdgcn_sched_barrier(0); VDB_EPI_J(I, G4, 1, NN) __builtin_amdgcn_sched_barrier(0);    \
+        VDB_EPI_J(I, G4, 2, NN) __builtin_amdgcn_sched_barrier(0); VDB_EPI_J(I, G4, 3, NN) __builtin_amdgcn_sched_barrier(0);    \
     }
-#define VDB_EPI_I(I)                                                                                   \
+#define VDB_EPI_I(I, NN)                                                                               \
     {                                                                                                  \
         const uint32_t vbits = (uint32_t)(val[(I) >> 1] >> (32 * ((I) & 1) + 4 * h));                  \
         const uint32_t rowt = wr * 128 + (I) * 32 + 4 * h;              /* tile-row of element (g = 0, e = 0) */ \
-        VDB_EPI_G(I, 0) VDB_EPI_G(I, 1) VDB_EPI_G(I, 2) VDB_EPI_G(I, 3)                                \
+        VDB_EPI_G(I, 0, NN) VDB_EPI_G(I, 1, NN) VDB_EPI_G(I, 2, NN) VDB_EPI_G(I, 3, NN)                \
     }
-            VDB_EPI_I(0) VDB_EPI_I(1) VDB_EPI_I(2) VDB_EPI_I(3)
+            // two copies of the scoring code, chosen once per tile: with the NaN test per group and without it
+            if (no_nan) { VDB_EPI_I(0, 1) VDB_EPI_I(1, 1) VDB_EPI_I(2, 1) VDB_EPI_I(3, 1) }
+            else { VDB_EPI_I(0, 0) VDB_EPI_I(1, 0) VDB_EPI_I(2, 0) VDB_EPI_I(3, 0) }
 #undef VDB_EPI_I
 #undef VDB_EPI_G
 #undef VDB_EPI_J
