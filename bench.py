@@ -1,12 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the FlatIndex hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1|c2|c3|c4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 and no torchrun environment (WORLD_SIZE unset) starts the N ranks ITSELF: before anything touches
+the GPU the process launches `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, relays rank 0's
+JSON line and exits with the child's code.  (`--dry-launch`: every rank prints its rank / world / local rank and exits
+without touching a GPU -- how the CPU test checks the launch.)
 
 Workloads (BASELINE.json `configs`); synthetic uniform[0,1) data like the reference's benches
 (benches/search_bench.rs:6-13), seeded.  One "step" = one batched search with queries and outputs resident in HBM.
 
+  c1  FlatIndex 10k x 128 f32, Euclidean, ONE query [0.5; 128], k = 10 -- benches/search_bench.rs:18-33, the literal
+      FlatIndex::search drop-in: microseconds per vdb_flat_search call (host pointers) and per device-resident call, the
+      oracle's single-core time beside them.
   c2 (default, the configuration BASELINE.json's metric is quoted on)
       FlatIndex 1M x 768 f32, cosine, batch = 256, k = 10.  --gpus N shards the SAME 1M rows ("scaling": "strong").
   c3  FlatIndex 10M x 768 f32, dot, batch = 1024, k = 100, row-sharded over 8 GPUs: every rank builds ITS 1.25M-row shard
@@ -16,6 +24,8 @@ Workloads (BASELINE.json `configs`); synthetic uniform[0,1) data
 
 With N > 1 the exchange (RCCL all-gather of the partial top-k + merge) runs behind the C ABI (include/vdb_shard.h);
 torch.distributed only launches the ranks, broadcasts the RCCL unique id and takes the MAX of the timings.
+"single_process_sharded" is the other form of the same index: ONE vdb_flat_index over all N GPUs inside rank 0's process
+(vdb_flat_create_sharded -- the object the reference's single server process would hold), timed while the other ranks idle.
 
 Prints ONE JSON line on rank 0 (the driver contract) with
   "roofline"        the dominant kernel, HIP-event timed on its launch stream, on BOTH axes of SURVEY 8(d) with the
@@ -30,7 +40,10 @@ import argparse
 import importlib.util
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -39,6 +52,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 CONFIGS = {
+    "c1": dict(rows=10_000, dim=128, batch=1, k=10, metric=0, scaling="strong",
+               workload="FlatIndex 10k x 128 f32, k=10, Euclidean, single query [0.5; 128] (BASELINE configs[0], benches/search_bench.rs:18-33)"),
     "c2": dict(rows=1_000_000, dim=768, batch=256, k=10, metric=1, scaling="strong",
                workload="FlatIndex 1M x 768 f32, cosine, batch=256 queries, k=10 (BASELINE configs[1])"),
     "c3": dict(rows_per_rank=1_250_000, dim=768, batch=1024, k=100, metric=2, scaling="weak",
@@ -114,6 +129,120 @@ def host_rows(n_rows, dim, device, data=None):
     return out
 
 
+def free_port():
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a child job.  Nothing in this process has touched
+    the GPU yet (importing torch does not), and it never does: it only relays the child's output and exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def newest_pmc_tag():
+    """Tag (e.g. 'r03_b') of the newest profiles/r*_pmc_fused.json: the only PMC pass bench.py may quote traffic from."""
+    import glob
+    import re
+    tags = []
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fused.json")):
+        m = re.match(r"(r\d+_[a-z]+)_pmc_fused\.json$", os.path.basename(f))
+        if m:
+            tags.append(m.group(1))
+    return max(tags) if tags else None
+
+
+def run_c1(args, vdb, device):
+    """BASELINE configs[0] at its own shape (benches/search_bench.rs:18-33): 10,000 x 128 uniform[0,1) rows, Euclidean, k = 10,
+    ONE query [0.5; 128].  This is Index::search itself -- one vdb_flat_search call per query -- so what is reported is the
+    latency of a call, host pointers in and out (the literal drop-in) and device-resident, with the oracle's time beside it."""
+    import ctypes
+    cfg = CONFIGS["c1"]
+    n, dim, k = args.rows or cfg["rows"], args.dim or cfg["dim"], args.k or cfg["k"]
+    rows = np.random.default_rng(0).random((n, dim), dtype=np.float32)          # search_bench.rs:6-13, seeded
+    q = np.full((dim,), 0.5, dtype=np.float32)                                 # search_bench.rs:27
+    index = vdb.GpuFlatIndex(vdb.DistanceMetric(cfg["metric"]), device=device.index or 0, keep_host_copy=False)
+    index.add_bulk(rows)
+    index.flush()
+    L, h = vdb._ffi.lib(), index._h
+    fp = ctypes.POINTER(ctypes.c_float)
+    out_i = np.zeros(k, dtype=np.uint64)
+    out_d = np.zeros(k, dtype=np.float32)
+    out_c = ctypes.c_size_t()
+
+    def host_call():
+        rc = L.vdb_flat_search(h, q.ctypes.data_as(fp), dim, k, out_i.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                               out_d.ctypes.data_as(fp), ctypes.byref(out_c))
+        assert rc == 0, vdb._ffi.last_error()
+
+    q_t = torch.from_numpy(q[None, :]).to(device)
+    d_i = torch.empty((1, k), dtype=torch.int64, device=device)
+    d_d = torch.empty((1, k), dtype=torch.float32, device=device)
+    d_c = torch.empty((1,), dtype=torch.int32, device=device)
+    torch.cuda.synchronize()
+
+    def dev_call():
+        index.search_batch_device(q_t.data_ptr(), 1, dim, k, d_i.data_ptr(), d_d.data_ptr(), d_c.data_ptr())
+
+    def lat(fn, w, kk):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize()
+        ts = []
+        t_all = time.perf_counter()
+        for _ in range(kk):
+            t1 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t1)
+        t_all = time.perf_counter() - t_all
+        ts.sort()
+        return t_all / kk, ts[len(ts) // 2], ts[int(len(ts) * 0.99)]
+
+    steps, warm = max(args.steps, 1), max(args.warmup, 1)
+    h_mean, h_med, h_p99 = lat(host_call, warm, steps)
+    stats = index.last_stats()
+    d_mean, d_med, d_p99 = lat(dev_call, warm, steps)
+    import oracle
+    oracle.lib()
+    t1 = time.perf_counter()
+    n_cpu = 0
+    while n_cpu < 20 or time.perf_counter() - t1 < min(args.cpu_seconds, 3.0):
+        oi, od = oracle.flat_search(cfg["metric"], rows, q, k)
+        n_cpu += 1
+    t_cpu = (time.perf_counter() - t1) / n_cpu
+    exact = bool(int(out_c.value) == len(oi) and np.array_equal(oi, out_i[:len(oi)]) and np.array_equal(od.view(np.uint32), out_d[:len(od)].view(np.uint32)))
+    exact_dev = bool(np.array_equal(d_i.cpu().numpy()[0].astype(np.uint64), oi) and np.array_equal(d_d.cpu().numpy()[0].view(np.uint32), od.view(np.uint32)))
+    alg_bytes = 4.0 * n * dim + 4.0 * dim
+    line = {
+        "metric": f"QPS of single-query FlatIndex::search, {n}x{dim} f32 euclidean k={k} (one vdb_flat_search call per query; latency in config.us_per_search)",
+        "value": round(1.0 / h_mean, 1), "unit": "queries/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+        "ms_per_step": round(1e3 * h_mean, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32 (f32-input MFMA scores of every row -- the dense path of indexes up to 16384 rows -- then the exact f32 re-rank)",
+        "data": "synthetic",
+        "config": {"workload": cfg["workload"], "name": "c1", "n_rows": n, "dim": dim, "batch": 1, "k": k, "distance": "euclidean",
+                   "inputs": "value: host pointers in and out (vdb_flat_search, the literal Index::search drop-in); device_resident: queries and outputs in HBM",
+                   "us_per_search": {"host_pointers": {"mean": round(1e6 * h_mean, 2), "median": round(1e6 * h_med, 2), "p99": round(1e6 * h_p99, 2)},
+                                     "device_resident": {"mean": round(1e6 * d_mean, 2), "median": round(1e6 * d_med, 2), "p99": round(1e6 * d_p99, 2)}}},
+        "recall_at_k": float(oracle.recall(oi, out_i[:k])), "path_stats": stats,
+        "roofline": {"bound": "hbm", "achieved": round(alg_bytes / d_mean / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(alg_bytes / d_mean / 1e9 / PEAK_HBM_GBS, 6), "traffic": None,
+                     "note": "5.12 MB per query: the call is bound by launch and synchronisation latency (five short kernels and one "
+                             "host sync), not by a roofline; the fraction is quoted on the device-resident call for completeness"},
+        "cpu_baseline": {"value": round(1.0 / t_cpu, 2), "unit": "queries/s", "cores": 1, "kind": "port",
+                         "us_per_search": round(1e6 * t_cpu, 1),
+                         "sample": f"{n_cpu} searches of the same query, {n_cpu * t_cpu:.2f} s; oracle/flat_oracle.c",
+                         "host_cpus": os.cpu_count(), "ids_and_distances_bit_identical": exact,
+                         "device_resident_call_bit_identical": exact_dev},
+    }
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,10 +260,18 @@ def main():
     ap.add_argument("--no-gauss", action="store_true", help="skip the side measurement on unit-normalised Gaussian rows")
     ap.add_argument("--no-shadow", action="store_true", help="skip the side measurement with the opt-in bf16 shadow rows (vdb_flat_set_shadow)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-batches-in-flight side measurement (keeps a profile's per-kernel averages synchronous)")
+    ap.add_argument("--no-single-process", action="store_true", help="skip the ONE-index-over-all-GPUs-in-one-process side measurement (vdb_flat_create_sharded)")
+    ap.add_argument("--lean", action="store_true", help="headline only: every side measurement off (profiling runs)")
     ap.add_argument("--data", default="uniform", choices=["uniform", "gauss"], help="distribution of the HEADLINE index")
     ap.add_argument("--screen", type=int, default=1, help="1: bf16 screening tier first (default); 0: f32 MFMA tier only")
-    ap.add_argument("--backend", default="nccl", help="nccl = RCCL behind the C ABI (default); gloo: the torch.distributed mirror of the call pattern, to rehearse several ranks on one GPU")
+    ap.add_argument("--dry-launch", action="store_true", help="print this rank's RANK / WORLD_SIZE / LOCAL_RANK as a JSON line and exit (no GPU is touched)")
     args = ap.parse_args()
+    if args.lean:
+        args.no_cpu = args.no_f32_tier = args.no_gauss = args.no_shadow = args.no_pipelined = args.no_single_process = True
+
+    # ---- `--gpus N` outside torchrun: launch the N ranks (before any GPU call in this process)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     global DATA
     DATA = args.data
@@ -142,24 +279,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": True, "rank": rank, "world": world, "local_rank": local_rank, "gpus": args.gpus,
+                          "master": f'{os.environ.get("MASTER_ADDR", "")}:{os.environ.get("MASTER_PORT", "")}'}), flush=True)
+        return
     if world != args.gpus and world > 1:
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)     # rehearsal: several ranks may share one GPU
+    if world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} GPU(s) visible; RCCL needs one device per rank")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    vdb = load_package()
+    vdb.build()
+    if args.config == "c1":
+        if world > 1:
+            raise SystemExit("config c1 is a single-query, single-GPU latency measurement")
+        return run_c1(args, vdb, device)
+    gloo = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        gloo = dist.new_group(backend="gloo")                       # host-side waits that must not park a kernel on the GPUs
 
-    vdb = load_package()
-    vdb.build()
-    from vectordb_from_scratch_amd.sharded import (ShardGroup, ShardedSearcher, gpu_local_search, group_search, shard_range)
+    from vectordb_from_scratch_amd.sharded import ShardGroup, gpu_local_search, group_search, shard_range
 
     dim = args.dim or cfg["dim"]
     B = args.batch or cfg["batch"]
@@ -194,29 +339,24 @@ def main():
                 "metadata_attach_ms": round(1e3 * (t2 - t1), 2), "compile_filter_ms": round(1e3 * (t3 - t2), 3),
                 "mask_upload_ms": round(1e3 * (t4 - t3), 3)}
 
-    # ---- the search path: N = 1 the plain device call; N > 1 the C-ABI shard group (RCCL) or, for rehearsals, its mirror
+    # ---- the search path: N = 1 the plain device call; N > 1 the C-ABI shard group (RCCL), one process per GPU
     mptr = mask_t.data_ptr() if mask_t is not None else 0
     group, rccl_ranks = None, None
-    shard_note = None
-    if world > 1 and args.backend == "nccl":
-        # every rank must take the same path: agree on whether the C-ABI group came up everywhere
+    if world > 1:
+        # every rank must take the same path: agree on whether the C-ABI group came up everywhere -- and stop if not
         try:
             group = ShardGroup.from_torch_distributed(local_rank)
             ok, why = 1, ""
-        except Exception as e:                                   # noqa: BLE001 -- reported in the line, never swallowed
+        except Exception as e:                                   # noqa: BLE001 -- reported, never swallowed
             group, ok, why = None, 0, f"{type(e).__name__}: {e}"
         flag = torch.tensor([ok], dtype=torch.int32, device=device)
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            group = None
-            shard_note = ("C-ABI shard group could not be created on every rank (" + (why or "another rank failed") +
-                          "); this run used the torch.distributed mirror of the same call pattern")
-    if group is not None:
+            raise SystemExit(f"rank {rank}: the C-ABI shard group (RCCL) could not be created on every rank ({why or 'another rank failed'})")
         rccl_ranks = group.world()
         search = group_search(group, index, mask_ptr=mptr, mask_bits=mask_bits)
     else:
-        searcher = ShardedSearcher(gpu_local_search(index, mask_ptr=mptr, mask_bits=mask_bits, reuse_outputs=True), rank=rank, world=world)
-        search = searcher.search_batch
+        search = gpu_local_search(index, mask_ptr=mptr, mask_bits=mask_bits, reuse_outputs=True)
 
     def step(q=None):
         return search(queries if q is None else q, k)
@@ -243,16 +383,19 @@ def main():
 
     # ---- roofline of the dominant kernel, HIP events on its launch stream (vdb_flat_set_profile).
     def kernel_ms_of(ix, fn, n_iter, rows_local):
-        # average duration of ONE launch of the dominant kernel (a batch above 256 queries takes several passes, and
-        # the counter sums their launches; rows_scanned / shard rows = launches of that search)
+        # average duration of ONE launch of the dominant kernel (a batch above the kernel's query tile takes several
+        # passes, and the counter sums their launches: stats["filter_launches"])
         ix.set_profile(True)
         ns = []
         for _ in range(n_iter):
             fn()
             st_ = ix.last_stats()
-            ns.append(st_["fused_kernel_ns"] / max(1, round(st_["rows_scanned"] / max(rows_local, 1))))
+            ns.append(st_["fused_kernel_ns"] / max(1, launches_of(st_, rows_local)))
         ix.set_profile(False)
         return float(np.mean(ns)) / 1e6
+
+    def launches_of(st_, rows_local):
+        return max(1, round(st_["rows_scanned"] / max(rows_local, 1)))
 
     local_rows = hi - lo
     # ---- the f32-exact tier FIRST: the same index and queries with every score on the f32-input MFMA (SURVEY 8(d)'s f32
@@ -276,18 +419,25 @@ def main():
 
     n_prof = max(3, min(args.steps, 10))
     kern_ms = kernel_ms_of(index, step, n_prof, local_rows)
-    b_launch = min(B, 256)                                      # queries of one launch (a pass handles up to 256)
+    n_launch = launches_of(stats, local_rows)                   # filter-pass launches of one step
+    b_launch = -(-B // n_launch)                                # queries served by one launch (one fetch of the rows)
     alg_flops = 2.0 * b_launch * local_rows * dim               # 2*B*N*d per launch
     alg_bytes = 4.0 * local_rows * dim + 4.0 * b_launch * dim   #              4*N*d + 4*B*d per launch
     screened = bool(stats.get("bf16_screen"))
+    # traffic: PMC bytes per launch of the profiled run profiles/traffic.json cites -- quoted ONLY when that run is the newest
+    # PMC pass under profiles/ (a line must not carry an older tree's counters)
     traffic, traffic_src = None, None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp) and world == 1 and args.config == "c2" and n_rows == CONFIGS["c2"]["rows"] and dim == 768:
         try:
             tj = json.load(open(tp))
             key = "hbm_bytes_per_launch_bf16_screen" if screened else "hbm_bytes_per_launch"
-            traffic = tj.get(key)
-            traffic_src = (tj.get(key + "_detail") or {}).get("source")
+            det = tj.get(key + "_detail") or {}
+            if screened and det.get("tag") != newest_pmc_tag():
+                traffic_src = f"not quoted: profiles/traffic.json cites {det.get('tag')}, the newest PMC pass under profiles/ is {newest_pmc_tag()}"
+            else:
+                traffic = tj.get(key)
+                traffic_src = det.get("source") or tj.get("source")
         except Exception:
             traffic = None
 
@@ -306,10 +456,13 @@ def main():
                                         "reported in f32_exact_tier")
             axes["bf16_mfma"] = {"achieved": round(tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_MFMA_TFLOPS, 4)}
             b = axes["hbm"]
+            wide = b_launch > 256
             r = {"bound": "hbm", "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"],
-                 "kernel": "fused_bf16p_kernel (8 waves, 256 rows x 256 queries, f32 rows by LDS-DMA into a 3-image ring, one mid-stage "
-                           "barrier per K stage, bf16 MFMA 32x32x16 scores, threshold filter"
-                           + ("; Dot / Euclid instance with per-row error margins)" if metric != 1 else ")")}
+                 "kernel": ("fused_bf16w_kernel (8 waves, 128 rows x 512 queries per workgroup: every fetched row tile serves 512 queries; "
+                            if wide else "fused_bf16p_kernel (8 waves, 256 rows x 256 queries, ") +
+                           "f32 rows by LDS-DMA into a 3-image ring, one mid-stage barrier per K stage, bf16 MFMA 32x32x16 scores, threshold filter"
+                           + ("; Dot / Euclid instance with per-row error margins)" if metric != 1 else ")"),
+                 "queries_per_launch": b_launch, "launches_per_step": n_launch}
         else:
             b = axes["f32_mfma"]
             r = {"bound": "mfma", "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"],
@@ -331,7 +484,10 @@ def main():
                     "roofline": roofline_of(k32, False)}
 
     # ---- two batches in flight (vdb_flat_search_batch_device_submit / _wait): what a server that keeps the GPU busy
-    # sees.  Same K batches, every one complete inside the timed region; reported beside the synchronous headline.
+    # sees.  Every batch completes inside its timed region.  The synchronous loop is RE-measured in the same leg,
+    # interleaved (pipelined, synchronous, pipelined, synchronous; each round K steps after 3 of its own kind): at the
+    # driver's 20-step length a single round of either kind moves by several per cent with the clock state the previous
+    # leg left behind, and only rounds taken side by side say which form is faster.
     pipelined = None
     if world == 1 and not args.no_pipelined:
         bufs = [(torch.empty((B, k), dtype=torch.int64, device=device), torch.empty((B, k), dtype=torch.float32, device=device),
@@ -350,29 +506,45 @@ def main():
                 t = t2
             index.search_batch_device_wait(t)
 
-        run_pipelined(max(args.warmup, 2))
-        barrier()
-        t1 = time.perf_counter()
-        run_pipelined(args.steps)
-        barrier()
-        el = time.perf_counter() - t1
+        def run_sync(n):
+            for _ in range(n):
+                step()
+
+        def one_round(fn):
+            fn(3)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            fn(args.steps)
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t1) / args.steps
+
+        run_pipelined(max(args.warmup, 4))                            # both workspaces and streams have run before anything is timed
+        rp, rs = [], []
+        for _ in range(3):
+            rp.append(one_round(run_pipelined))
+            rs.append(one_round(run_sync))
         same = bool(torch.equal(bufs[(args.steps - 1) & 1][0], out[0]) and
                     torch.equal(bufs[(args.steps - 1) & 1][1].view(torch.int32), out[1].view(torch.int32)))
-        pipelined = {"value": round(B * args.steps / el, 2), "unit": "queries/s", "ms_per_step": round(1e3 * el / args.steps, 4),
+        mp_, ms_ = float(np.median(rp)), float(np.median(rs))
+        pipelined = {"value": round(B / (mp_ * 1e-3), 2), "unit": "queries/s", "ms_per_step": round(mp_, 4),
                      "in_flight": 2, "results_identical_to_synchronous_path": same,
-                     "note": "vdb_flat_search_batch_device_submit / _wait: batch i+1 is submitted before batch i is waited for"}
+                     "rounds_ms_per_step": {"pipelined": [round(x, 4) for x in rp], "synchronous_interleaved": [round(x, 4) for x in rs]},
+                     "synchronous_interleaved_ms_per_step": round(ms_, 4),
+                     "note": "vdb_flat_search_batch_device_submit / _wait: batch i+1 is submitted before batch i is waited for; medians of 3 "
+                             "interleaved rounds of --steps batches each (the headline `value` stays the contract's single W + K run)"}
 
     # ---- opt-in bf16 shadow rows (vdb_flat_set_shadow): +50 % device memory, the filter pass streams 2 bytes per element.
     # Same index, same queries, same results; reported beside the headline (which keeps the f32 rows), never as `value`.
     shadow = None
     if world == 1 and screened and not args.no_shadow and dim % 64 == 0 and mask_t is None:
         index.set_shadow(True)
-        els, outs = timed(step, max(2, args.warmup // 2), args.steps)
+        els, outs = timed(step, max(3, args.warmup), args.steps)
         sst = index.last_stats()
         outs = tuple(t.clone() for t in outs)
         ks = kernel_ms_of(index, step, n_prof, local_rows)
         index.set_shadow(False)
-        sh_bytes = 2.0 * local_rows * dim + 2.0 * b_launch * dim
+        sh_bytes = 2.0 * local_rows * dim + 2.0 * min(B, 256) * dim
+        sh_flops = 2.0 * min(B, 256) * local_rows * dim
         shadow = {"value": round(B * args.steps / els, 2), "unit": "queries/s", "ms_per_step": round(1e3 * els / args.steps, 4),
                   "used": bool(sst.get("shadow_rows")), "extra_device_memory_bytes": int(2 * local_rows * dim),
                   "results_identical_to_default_path": bool(torch.equal(outs[0], out[0]) and torch.equal(outs[1].view(torch.int32), out[1].view(torch.int32))),
@@ -381,22 +553,34 @@ def main():
                   "kernel_ms": round(ks, 4),
                   "axes": {"hbm": {"achieved": round(sh_bytes / (ks * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": round(sh_bytes / (ks * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": sh_bytes},
-                           "bf16_mfma": {"achieved": round(alg_flops / (ks * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                         "frac": round(alg_flops / (ks * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}},
-                  "note": "neither axis binds alone: DMA only 0.26 ms, MFMA + fragment reads only 0.28 ms (the clock the chip holds under "
-                          "a dense bf16 MFMA loop), the per-tile epilogue ~0.09 ms with one wave per SIMD (DESIGN.md 4.2)"}
+                           "bf16_mfma": {"achieved": round(sh_flops / (ks * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": round(sh_flops / (ks * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}},
+                  "note": "neither axis binds alone: DMA only 0.26 ms, MFMA + fragment reads only 0.27 ms (the clock the chip holds under "
+                          "a dense bf16 MFMA loop), the per-tile epilogue ~0.08 ms with one wave per SIMD (DESIGN.md 4.3)"}
 
-    # ---- the harder distribution of SURVEY 8(d): unit-normalised Gaussian rows, Gaussian queries, same size
+    # ---- the harder distribution of SURVEY 8(d): unit-normalised Gaussian rows, Gaussian queries, same size.  Three rounds,
+    # each followed by a round on the UNIFORM index in the same clock state (control): the comparison the line makes is
+    # between those pairs, not with the headline taken a minute earlier.
     gauss = None
     if world == 1 and DATA == "uniform" and args.config == "c2" and not args.no_gauss:
         gidx = build_index(vdb, metric, 0, n_rows, n_rows, dim, device, local_rank, data="gauss")
         gq = gen_queries(B, dim, device, data="gauss")
         gsearch = gpu_local_search(gidx, reuse_outputs=True)
-        gel, gout = timed(lambda: gsearch(gq, k), args.warmup, args.steps)
+        gel, gout = timed(lambda: gsearch(gq, k), max(args.warmup, 5), args.steps)
+        rg, ru = [1e3 * gel / args.steps], []
+        for r_ in range(3):
+            if r_:
+                rg.append(1e3 * timed(lambda: gsearch(gq, k), 3, args.steps)[0] / args.steps)
+            ru.append(1e3 * timed(step, 3, args.steps)[0] / args.steps)
+        gout = gsearch(gq, k)
         gst = gidx.last_stats()
-        gk = kernel_ms_of(gidx, lambda: gsearch(gq, k), 3, n_rows)
-        gauss = {"value": round(B * args.steps / gel, 2), "unit": "queries/s", "ms_per_step": round(1e3 * gel / args.steps, 4),
+        gk = kernel_ms_of(gidx, lambda: gsearch(gq, k), n_prof, n_rows)
+        uk = kernel_ms_of(index, step, n_prof, local_rows)
+        mg_ = float(np.median(rg))
+        gauss = {"value": round(B / (mg_ * 1e-3), 2), "unit": "queries/s", "ms_per_step": round(mg_, 4),
                  "kernel_ms": round(gk, 4), "hbm_frac": round(alg_bytes / (gk * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if gk > 0 else None,
+                 "rounds_ms_per_step": {"gauss": [round(x, 4) for x in rg], "uniform_interleaved": [round(x, 4) for x in ru]},
+                 "uniform_interleaved_ms_per_step": round(float(np.median(ru)), 4), "uniform_interleaved_kernel_ms": round(uk, 4),
                  "path_stats": {x: gst[x] for x in ("uncertified", "rethreshold_queries", "f32_tier_queries", "exact_queries", "pool_overflows")},
                  "data": "unit-normalised Gaussian rows, Gaussian queries (seeded)"}
         if not args.no_cpu:
@@ -410,14 +594,15 @@ def main():
             gauss["ids_and_distances_bit_identical_to_oracle"] = ok
             gauss["queries_checked"] = 2
             del grows
-        del gidx
+        del gidx, gsearch, gout
 
     # ---- the host-pointer entry point (vdb_flat_search_batch): queries cross PCIe in, results out, per batch.
     # Reported beside the headline, never as `value`.
     host_io = None
     if world == 1 and not args.no_cpu and mask_t is None:
         q_pin = queries.cpu().numpy()
-        index.search_batch_arrays(q_pin, k)
+        for _ in range(3):
+            index.search_batch_arrays(q_pin, k)
         t1 = time.perf_counter()
         n_io = 10
         for _ in range(n_io):
@@ -425,6 +610,33 @@ def main():
         el = time.perf_counter() - t1
         host_io = {"value": round(B * n_io / el, 2), "unit": "queries/s", "ms_per_step": round(1e3 * el / n_io, 4),
                    "note": "host numpy arrays in and out (H2D of the queries, D2H of ids/distances/counts inside the step)"}
+
+    # ---- ONE index over all N GPUs inside ONE process (vdb_flat_create_sharded): the object the reference's single server
+    # process would hold behind `impl Index`.  Rank 0 builds it over devices 0..N-1 and times the same batch while the other
+    # ranks idle on a host-side (gloo) wait -- no kernel of theirs sits on the GPUs.  Bounded: a watchdog thread gives up
+    # after --single-process-timeout seconds, the line says so, and the headline above is unaffected either way.
+    single, leg_hung = None, False
+    if not args.no_single_process and args.config in ("c2", "c4") and mask_t is None:
+        if world > 1:
+            torch.distributed.barrier(group=gloo)
+        if rank == 0:
+            box = {}
+
+            def leg():
+                try:
+                    box["r"] = single_process_leg(vdb, metric, n_rows, dim, B, k, world, args, out)
+                except Exception as e:                               # noqa: BLE001 -- reported in the line
+                    box["r"] = {"error": f"{type(e).__name__}: {e}"}
+
+            th = threading.Thread(target=leg, daemon=True)
+            th.start()
+            th.join(240.0)
+            single = box.get("r") or {"error": "timed out after 240 s (the leg was abandoned; the headline is unaffected)"}
+            leg_hung = th.is_alive()
+        if world > 1:
+            flag = torch.tensor([1 if leg_hung else 0], dtype=torch.int32)
+            torch.distributed.broadcast(flag, src=0, group=gloo)
+            leg_hung = bool(flag.item())
 
     # ---- cpu_baseline (rank 0, N=1 only): the oracle restatement of the reference, 1 core, bounded sample
     cpu, recall, parity_n = None, None, None
@@ -481,9 +693,8 @@ def main():
             "data": "synthetic" if DATA == "uniform" else "synthetic (unit-normalised Gaussian rows)",
             "config": {"workload": cfg["workload"], "name": args.config,
                        "n_rows": n_rows, "rows_per_gpu": local_rows, "dim": dim, "batch": B, "k": k, "distance": mname,
-                       "sharding": f"rows/{world}, exchange = RCCL all-gather + merge behind the C ABI (vdb_flat_search_batch_sharded)"
-                                   if group is not None else (f"rows/{world} ({args.backend} mirror of the call pattern)" if world > 1 else "single GPU"),
-                       "sharding_note": shard_note,
+                       "sharding": f"rows/{world}, one process per GPU, exchange = RCCL all-gather + merge behind the C ABI (vdb_flat_search_batch_sharded)"
+                                   if group is not None else "single GPU",
                        "inputs": "queries and outputs resident in HBM",
                        "arithmetic": ("rows, queries and every reported distance are f32 (exact re-rank in the reference's operation "
                                       "order, bit-identical to the f32 oracle); candidates are RANKED by bf16-MFMA scores under an error "
@@ -500,6 +711,7 @@ def main():
             "f32_exact_tier": f32_tier,
             "gauss_dataset": gauss,
             "pcie_inclusive": host_io,
+            "single_process_sharded": single,
             "cpu_baseline": cpu,
         }
         if args.config == "c2":
@@ -508,9 +720,63 @@ def main():
             line["parity"] = parity_n
         print(json.dumps(line), flush=True)
     if world > 1:
-        torch.distributed.barrier()
+        torch.distributed.barrier(group=gloo)
+    if leg_hung:
+        # an abandoned single-process leg still holds a thread inside the library: no teardown, no interpreter shutdown -- the
+        # line is out and the ranks are in step, so every rank leaves at once
+        sys.stdout.flush()
+        os._exit(0)
+    if world > 1:
         del group
         torch.distributed.destroy_process_group()
+
+
+def single_process_leg(vdb, metric, n_rows, dim, B, k, n_dev, args, ref_out):
+    """ONE GpuFlatIndex(devices=[0..n_dev-1]) in this process: build, W + K timed steps, results against the headline's."""
+    dev0 = torch.device("cuda", 0)
+    t_b = time.perf_counter()
+    idx = vdb.GpuFlatIndex(vdb.DistanceMetric(metric), devices=list(range(n_dev)), keep_host_copy=False)
+    idx.reserve(n_rows, dim)
+    chunk = min(CHUNK, n_rows)
+    with torch.cuda.device(dev0):
+        for c in range((n_rows + chunk - 1) // chunk):
+            c0, c1 = c * chunk, min((c + 1) * chunk, n_rows)
+            block = gen_chunk(c, c1 - c0, dim, dev0)
+            torch.cuda.synchronize(dev0)
+            idx.add_bulk_device(block.data_ptr(), c1 - c0, dim, first_id=c0)
+            del block
+        idx.flush()
+        build_s = time.perf_counter() - t_b
+        q = gen_queries(B, dim, dev0)
+        o_i = torch.empty((B, k), dtype=torch.int64, device=dev0)
+        o_d = torch.empty((B, k), dtype=torch.float32, device=dev0)
+        o_c = torch.empty((B,), dtype=torch.int32, device=dev0)
+        torch.cuda.synchronize(dev0)
+
+        def one():
+            idx.search_batch_device(q.data_ptr(), B, dim, k, o_i.data_ptr(), o_d.data_ptr(), o_c.data_ptr())
+
+        res = {"shards": idx.shards(), "rows_per_shard": [idx.shard_len(g) for g in range(idx.shards())], "build_s": round(build_s, 2)}
+        modes = [("rccl", vdb.GpuFlatIndex.EXCHANGE_RCCL), ("peer", vdb.GpuFlatIndex.EXCHANGE_PEER)]
+        for name, mode in modes:
+            idx.set_exchange(mode)
+            for _ in range(max(args.warmup, 3)):
+                one()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                one()
+            el = time.perf_counter() - t1
+            st = idx.shard_stats()
+            same = bool(torch.equal(o_i.cpu(), ref_out[0].cpu()) and torch.equal(o_d.cpu().view(torch.int32), ref_out[1].cpu().view(torch.int32)))
+            res[name] = {"value": round(B * args.steps / el, 2), "unit": "queries/s", "ms_per_step": round(1e3 * el / args.steps, 4),
+                         "exchanges_per_step": st["exchanges"], "rccl_ranks": st["rccl_ranks"],
+                         "host_enqueue_us": round(st["host_enqueued_ns"] / 1e3, 1),
+                         "results_identical_to_headline": same}
+        res["note"] = ("vdb_flat_create_sharded: ONE vdb_flat_index whose rows are dealt to the listed GPUs inside this process (a worker thread "
+                       "and a stream per shard); 'rccl' = grouped ncclAllGather over in-process communicators (the default), 'peer' = "
+                       "hipMemcpyPeerAsync of every shard's packed block into device 0; synchronous steps, queries and outputs on device 0")
+    del idx
+    return res
 
 
 if __name__ == "__main__":

@@ -59,6 +59,42 @@ typedef struct vdb_flat_index vdb_flat_index; /* opaque; owns all device and sta
 int vdb_flat_create(int metric, int device, vdb_flat_index **out);
 void vdb_flat_destroy(vdb_flat_index *h);
 
+/*
+ * ONE index over several GPUs of one node, in ONE process -- the form the reference's seam needs: a server process holds a
+ * single `VectorStore<I: Index>` behind one RwLock (src/storage.rs:83,:116-127, src/server/mod.rs:13-16), so the object that
+ * implements `Index` must itself own the row shards (BASELINE.json north_star: "the index shards by database row across the
+ * 8 GPUs of one node, each GPU producing a partial top-k that is merged after an RCCL all-gather over xGMI").
+ *
+ * The handle is an ordinary vdb_flat_index: every call below takes it.  Rows are dealt to the `n_devices` shards (one per
+ * entry of `devices`; bulk loads in contiguous blocks, vdb_shard_range in vdb_shard.h; single adds to the shard that already
+ * holds the id, else to the emptiest).  A batched search runs the local pipeline of every shard concurrently (one host
+ * worker thread and one stream per shard), exchanges the packed partial top-k (ids | distances | counts | status,
+ * nq*k*12 bytes per shard) and merges by (distance, id) on devices[0], where queries and outputs live.  Results are
+ * identical to a single-GPU index over the same rows, bit for bit; errors keep the reference's semantics (a zero-norm row
+ * on ANY shard fails the batch, src/flat_index.rs:57-60).
+ *
+ * Exchange (vdb_flat_set_exchange): VDB_EXCHANGE_RCCL -- in-process RCCL communicators (ncclCommInitAll), one grouped
+ * ncclAllGather per batch; the default whenever the listed devices are distinct.  VDB_EXCHANGE_PEER -- each shard's stream
+ * copies its packed block straight into devices[0]'s gather buffer (hipMemcpyPeerAsync over xGMI); the default when a device
+ * is listed more than once (several shards on one GPU: how the multi-shard logic is tested on a one-GPU box -- RCCL refuses
+ * two ranks on one device).
+ *
+ * Not available on a sharded handle: the two-half / ticket forms of the device search (begin/finish, submit/wait),
+ * vdb_flat_distances_batch, the vdb_flat_debug_* probes and vdb_flat_search_batch_sharded (that one is the
+ * process-per-GPU form of the same exchange, vdb_shard.h); they return VDB_ERR_INVALID_ARGUMENT.
+ */
+int vdb_flat_create_sharded(int metric, const int *devices, size_t n_devices, vdb_flat_index **out);
+/* number of shards of the handle (1 for a plain vdb_flat_create handle) */
+size_t vdb_flat_shards(const vdb_flat_index *h);
+/* live rows of shard `shard` (sharded handle), or vdb_flat_len for a plain handle with shard == 0 */
+size_t vdb_flat_shard_len(const vdb_flat_index *h, size_t shard);
+enum { VDB_EXCHANGE_RCCL = 0, VDB_EXCHANGE_PEER = 1 };
+int vdb_flat_set_exchange(vdb_flat_index *h, int mode);
+/* Counters of the last search on a sharded handle: [0] exchanges performed (1, or 2 when a shard needed its host after the
+ * first tier), [1] shards, [2] exchange mode used, [3] ranks RCCL reports for the communicators (0 in peer mode),
+ * [4] host clock of the call (ns), [5] host clock until every shard's first tier was enqueued (ns). */
+int vdb_flat_shard_stats(const vdb_flat_index *h, uint64_t out[8]);
+
 /* Index::add(id, vector)  src/index.rs:13, src/flat_index.rs:38-41.
  * Copies the row.  An existing id is overwritten silently (HashMap::insert).
  * Like the reference there is NO dimension check at add: a row whose dimension

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 def test_shards_merge_equals_unsharded(metric, world):
     vdb = load_package()
     vdb.build()
-    from vectordb_from_scratch_amd.sharded import gpu_local_search, merge_topk_hip, merge_topk_torch, shard_range
+    from sharded_mirror import merge_topk_torch
+    from vectordb_from_scratch_amd.sharded import gpu_local_search, merge_topk_hip, shard_range
     rng = np.random.default_rng(100 + metric)
     n, d, B, k = 50_000, 48, 37, 10
     rows = rng.standard_normal((n, d)).astype(np.float32)
@@ -52,7 +53,7 @@ def test_packed_exchange_buffer_merge():
     vdb = load_package()
     vdb.build()
     from vectordb_from_scratch_amd import _ffi
-    from vectordb_from_scratch_amd.sharded import merge_topk_torch
+    from sharded_mirror import merge_topk_torch
     W, B, k = 3, 17, 10
     g = torch.Generator().manual_seed(5)
     words = B * (3 * k + 1) + 1

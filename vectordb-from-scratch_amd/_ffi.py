@@ -12,7 +12,7 @@ OK, ERR_DIMENSION_MISMATCH, ERR_INVALID_VECTOR, ERR_NAN, ERR_DEVICE, ERR_INVALID
 
 # every symbol include/vdb_flat.h declares
 SYMBOLS = [
-    "vdb_flat_create", "vdb_flat_destroy", "vdb_flat_add", "vdb_flat_add_bulk", "vdb_flat_add_bulk_device",
+    "vdb_flat_create", "vdb_flat_destroy", "vdb_flat_create_sharded", "vdb_flat_shards", "vdb_flat_shard_len", "vdb_flat_set_exchange", "vdb_flat_shard_stats", "vdb_flat_add", "vdb_flat_add_bulk", "vdb_flat_add_bulk_device",
     "vdb_flat_load_vector_file", "vdb_flat_remove", "vdb_flat_get_vector", "vdb_flat_len", "vdb_flat_metric", "vdb_flat_dim",
     "vdb_flat_reserve", "vdb_flat_flush", "vdb_flat_search", "vdb_flat_search_batch",
     "vdb_flat_search_batch_device", "vdb_flat_search_batch_device_begin", "vdb_flat_search_batch_device_finish", "vdb_flat_search_batch_device_submit", "vdb_flat_search_batch_device_wait", "vdb_flat_distances_batch", "vdb_merge_topk_device", "vdb_merge_topk_packed_device", "vdb_flat_set_profile", "vdb_flat_last_stats", "vdb_flat_last_stats_ex", "vdb_flat_set_screen", "vdb_flat_set_shadow", "vdb_flat_set_sample_cache", "vdb_flat_set_tiers", "vdb_flat_debug_screen_scores", "vdb_flat_debug_rows", "vdb_flat_debug_row_info", "vdb_flat_debug_last_thresholds", "vdb_flat_debug_cert_probe", "vdb_last_error",
@@ -69,6 +69,13 @@ def lib():
     L.vdb_flat_create.argtypes = [c.c_int, c.c_int, c.POINTER(vp)]
     L.vdb_flat_destroy.argtypes = [vp]
     L.vdb_flat_destroy.restype = None
+    L.vdb_flat_create_sharded.argtypes = [c.c_int, c.POINTER(c.c_int), sz, c.POINTER(vp)]
+    L.vdb_flat_shards.argtypes = [vp]
+    L.vdb_flat_shards.restype = sz
+    L.vdb_flat_shard_len.argtypes = [vp, sz]
+    L.vdb_flat_shard_len.restype = sz
+    L.vdb_flat_set_exchange.argtypes = [vp, c.c_int]
+    L.vdb_flat_shard_stats.argtypes = [vp, u64p]
     L.vdb_flat_add.argtypes = [vp, u64, fp, sz]
     L.vdb_flat_add_bulk.argtypes = [vp, u64p, u64, fp, sz, sz]
     L.vdb_flat_add_bulk_device.argtypes = [vp, u64p, u64, vp, sz, sz]

@@ -121,6 +121,7 @@ int vdb_flat_create(int metric, int device, vdb_flat_index** out) {
 
 void vdb_flat_destroy(vdb_flat_index* ix) {
     if (!ix) return;
+    if (ix->multi) { multi_destroy(ix); return; }
     (void)hipSetDevice(ix->device);
     (void)hipStreamSynchronize(ix->stream);
     free_store(ix);
@@ -145,6 +146,7 @@ void vdb_flat_destroy(vdb_flat_index* ix) {
 int vdb_flat_add(vdb_flat_index* ix, uint64_t id, const float* v, size_t dim) {
     return guarded([&]() -> int {
     if (!ix || (!v && dim)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    if (ix->multi) return multi_add(ix, id, v, dim);
     std::lock_guard<std::mutex> g(ix->mu);
     if (in_flight(ix)) return refuse_in_flight();
     int rc = set_device(ix);
@@ -157,6 +159,7 @@ int vdb_flat_add_bulk(vdb_flat_index* ix, const uint64_t* ids, uint64_t first_id
                       size_t dim) {
     return guarded([&]() -> int {
     if (!ix || (!rows && n && dim)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    if (ix->multi) return multi_add_bulk(ix, ids, first_id, rows, n, dim, false);
     std::lock_guard<std::mutex> g(ix->mu);
     if (in_flight(ix)) return refuse_in_flight();
     int rc = set_device(ix);
@@ -181,6 +184,7 @@ int vdb_flat_add_bulk_device(vdb_flat_index* ix, const uint64_t* ids, uint64_t f
     if (!ix || (!d_rows && n)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return VDB_OK;
     if (dim == 0) return fail(VDB_ERR_INVALID_ARGUMENT, "dim must be > 0");
+    if (ix->multi) return multi_add_bulk(ix, ids, first_id, d_rows, n, dim, true);
     std::lock_guard<std::mutex> g(ix->mu);
     if (in_flight(ix)) return refuse_in_flight();
     int rc = set_device(ix);
@@ -274,6 +278,7 @@ int vdb_flat_load_vector_file(vdb_flat_index* ix, const char* path, uint64_t fir
 int vdb_flat_remove(vdb_flat_index* ix, uint64_t id) {
     return guarded([&]() -> int {
     if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    if (ix->multi) return multi_remove(ix, id);
     std::lock_guard<std::mutex> g(ix->mu);
     if (in_flight(ix)) return refuse_in_flight();
     int rc = set_device(ix);
@@ -285,6 +290,7 @@ int vdb_flat_remove(vdb_flat_index* ix, uint64_t id) {
 int vdb_flat_get_vector(vdb_flat_index* ix, uint64_t id, float* out, size_t cap, size_t* dim) {
     return guarded([&]() -> int {
     if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    if (ix->multi) return multi_get_vector(ix, id, out, cap, dim);
     std::lock_guard<std::mutex> g(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
@@ -309,13 +315,14 @@ int vdb_flat_get_vector(vdb_flat_index* ix, uint64_t id, float* out, size_t cap,
     });
 }
 
-size_t vdb_flat_len(const vdb_flat_index* ix) { return ix ? ix->n_live + ix->misfits.size() : 0; }
+size_t vdb_flat_len(const vdb_flat_index* ix) { return !ix ? 0 : ix->multi ? multi_len(ix) : ix->n_live + ix->misfits.size(); }
 int vdb_flat_metric(const vdb_flat_index* ix) { return ix ? ix->metric : -1; }
-size_t vdb_flat_dim(const vdb_flat_index* ix) { return ix ? ix->dim : 0; }
+size_t vdb_flat_dim(const vdb_flat_index* ix) { return !ix ? 0 : ix->multi ? multi_dim(ix) : ix->dim; }
 
 int vdb_flat_reserve(vdb_flat_index* ix, size_t rows, size_t dim) {
     return guarded([&]() -> int {
     if (!ix || !dim) return fail(VDB_ERR_INVALID_ARGUMENT, "bad argument");
+    if (ix->multi) return multi_reserve(ix, rows, dim);
     std::lock_guard<std::mutex> g(ix->mu);
     if (in_flight(ix)) return refuse_in_flight();
     int rc = set_device(ix);
@@ -335,6 +342,7 @@ int vdb_flat_reserve(vdb_flat_index* ix, size_t rows, size_t dim) {
 int vdb_flat_flush(vdb_flat_index* ix) {
     return guarded([&]() -> int {
     if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    if (ix->multi) return multi_for_each(ix, [](vdb_flat_index* c) { return vdb_flat_flush(c); });
     std::lock_guard<std::mutex> g(ix->mu);
     if (in_flight(ix)) return refuse_in_flight();
     int rc = set_device(ix);
@@ -351,6 +359,7 @@ int vdb_flat_search_batch_device(vdb_flat_index* ix, const float* d_queries, siz
     return guarded([&]() -> int {
     if (!ix || (nq && (!d_queries || !d_out_counts || (k && (!d_out_ids || !d_out_dists)))))
         return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    if (ix->multi) return multi_search_device(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts, (hipStream_t)stream);
     std::lock_guard<std::mutex> g(ix->mu);
     return search_device(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts,
                          (hipStream_t)stream);
@@ -363,6 +372,7 @@ int vdb_flat_search_batch_device_begin(vdb_flat_index* ix, const float* d_querie
     return guarded([&]() -> int {
     if (!ix || (nq && (!d_queries || !d_out_counts || (k && (!d_out_ids || !d_out_dists)))))
         return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    if (ix->multi) return refuse_multi("vdb_flat_search_batch_device_begin");
     ix->mu.lock();
     if (ix->begin_locked) { ix->mu.unlock(); return fail(VDB_ERR_INVALID_ARGUMENT, "a search is already pending on this handle"); }
     if (in_flight(ix)) { ix->mu.unlock(); return refuse_in_flight(); }
@@ -393,6 +403,7 @@ int vdb_flat_search_batch_device_begin(vdb_flat_index* ix, const float* d_querie
 int vdb_flat_search_batch_device_finish(vdb_flat_index* ix, int* changed) {
     return guarded([&]() -> int {
     if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    if (ix->multi) return refuse_multi("vdb_flat_search_batch_device_finish");
     if (!ix->begin_locked) return fail(VDB_ERR_INVALID_ARGUMENT, "no search pending on this handle");
     int rc = guarded([&]() -> int { return search_part2(ix, changed); });
     publish_stats(ix);
@@ -409,6 +420,7 @@ int vdb_flat_search_batch_device_submit(vdb_flat_index* ix, const float* d_queri
     return guarded([&]() -> int {
     if (!ix || !ticket || (nq && (!d_queries || !d_out_counts || (k && (!d_out_ids || !d_out_dists)))))
         return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    if (ix->multi) return refuse_multi("vdb_flat_search_batch_device_submit");
     *ticket = -1;
     std::lock_guard<std::mutex> g(ix->mu);
     if (ix->begin_locked) return fail(VDB_ERR_INVALID_ARGUMENT, "a search is pending between begin and finish");
@@ -428,6 +440,7 @@ int vdb_flat_search_batch_device_submit(vdb_flat_index* ix, const float* d_queri
 int vdb_flat_search_batch_device_wait(vdb_flat_index* ix, int ticket) {
     return guarded([&]() -> int {
     if (!ix || ticket < 0 || ticket > 1) return fail(VDB_ERR_INVALID_ARGUMENT, "bad ticket");
+    if (ix->multi) return refuse_multi("vdb_flat_search_batch_device_wait");
     std::lock_guard<std::mutex> g(ix->mu);
     if (!ix->wsv[ticket].busy) return fail(VDB_ERR_INVALID_ARGUMENT, "no submitted search behind this ticket");
     int rc = set_device(ix);
@@ -447,6 +460,7 @@ int vdb_flat_search_batch(vdb_flat_index* ix, const float* queries, size_t nq, s
                           float* out_dists, size_t* out_counts) {
     return guarded([&]() -> int {
     if (!ix || (nq && (!queries || !out_counts))) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    if (ix->multi) return multi_search_host(ix, queries, nq, dim, ks, k, id_mask, mask_bits, kstride, out_ids, out_dists, out_counts);
     size_t kmax = k;
     if (ks) {
         kmax = 0;
@@ -527,6 +541,7 @@ int vdb_flat_distances_batch(vdb_flat_index* ix, const float* queries, size_t nq
                              const uint64_t* ids, float* out_dists) {
     return guarded([&]() -> int {
     if (!ix || !offsets || (nq && !queries)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    if (ix->multi) return refuse_multi("vdb_flat_distances_batch");
     const size_t total = offsets[nq];
     if (total && (!ids || !out_dists)) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
@@ -600,6 +615,7 @@ int vdb_merge_topk_packed_device(int device, const int32_t* d_packed, size_t npa
 int vdb_flat_set_profile(vdb_flat_index* ix, int on) {
     return guarded([&]() -> int {
     if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    if (ix->multi) return multi_for_each(ix, [on](vdb_flat_index* c) { return vdb_flat_set_profile(c, on); });
     std::lock_guard<std::mutex> g(ix->mu);
     int rc = set_device(ix);
     if (rc) return rc;
@@ -623,7 +639,7 @@ int vdb_flat_last_stats(const vdb_flat_index* ix, uint64_t out[8]) {
 int vdb_flat_last_stats_ex(const vdb_flat_index* ix, uint64_t* out, size_t n) {
     return guarded([&]() -> int {
     if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
-    for (size_t i = 0; i < n; ++i) out[i] = i < 16 ? ix->cur->stats[i] : 0;
+    for (size_t i = 0; i < n; ++i) out[i] = i < 16 ? (ix->multi ? ix->stats[i] : ix->cur->stats[i]) : 0;
     return VDB_OK;
     });
 }
@@ -632,6 +648,7 @@ int vdb_flat_last_stats_ex(const vdb_flat_index* ix, uint64_t* out, size_t n) {
 int vdb_flat_debug_screen_scores(vdb_flat_index* ix, const float* queries, size_t nq, size_t dim, int raw, float* out_scores,
                                  float* out_qinfo, double* out_consts) {
     return guarded([&]() -> int {
+    if (ix && ix->multi) return refuse_multi("vdb_flat_debug_screen_scores");
     if (!ix || !queries || !out_scores || !nq) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     if (nq > SUPER) return fail(VDB_ERR_INVALID_ARGUMENT, "at most %u queries per call", SUPER);
     std::lock_guard<std::mutex> g(ix->mu);
@@ -739,10 +756,11 @@ int vdb_flat_debug_screen_scores(vdb_flat_index* ix, const float* queries, size_
     });
 }
 
-size_t vdb_flat_debug_rows(const vdb_flat_index* ix) { return ix ? ix->row_ids.size() : 0; }
+size_t vdb_flat_debug_rows(const vdb_flat_index* ix) { return (ix && !ix->multi) ? ix->row_ids.size() : 0; }
 
 int vdb_flat_debug_last_thresholds(vdb_flat_index* ix, float* out, size_t nq) {
     return guarded([&]() -> int {
+    if (ix && ix->multi) return refuse_multi("vdb_flat_debug_last_thresholds");
     if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
     if (in_flight(ix)) return refuse_in_flight();
@@ -756,6 +774,7 @@ int vdb_flat_debug_last_thresholds(vdb_flat_index* ix, float* out, size_t nq) {
 
 int vdb_flat_debug_row_info(vdb_flat_index* ix, float* out, size_t n_rows) {
     return guarded([&]() -> int {
+    if (ix && ix->multi) return refuse_multi("vdb_flat_debug_row_info");
     if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
     if (in_flight(ix)) return refuse_in_flight();
@@ -777,6 +796,7 @@ int vdb_flat_debug_row_info(vdb_flat_index* ix, float* out, size_t n_rows) {
 
 int vdb_flat_debug_cert_probe(vdb_flat_index* ix, const uint32_t* qi, const float* T, const float* ek, size_t n, uint32_t* out) {
     return guarded([&]() -> int {
+    if (ix && ix->multi) return refuse_multi("vdb_flat_debug_cert_probe");
     if (!ix || !qi || !T || !ek || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> g(ix->mu);
     if (in_flight(ix)) return refuse_in_flight();
@@ -809,6 +829,7 @@ int vdb_flat_debug_cert_probe(vdb_flat_index* ix, const uint32_t* qi, const floa
 int vdb_flat_set_sample_cache(vdb_flat_index* ix, int on) {
     return guarded([&]() -> int {
     if (!ix || on < 0 || on > 1) return fail(VDB_ERR_INVALID_ARGUMENT, "on must be 0 or 1");
+    if (ix->multi) return multi_for_each(ix, [on](vdb_flat_index* c) { return vdb_flat_set_sample_cache(c, on); });
     std::lock_guard<std::mutex> g(ix->mu);
     if (in_flight(ix)) return refuse_in_flight();
     ix->sample_cache = on != 0;
@@ -825,6 +846,7 @@ int vdb_flat_set_sample_cache(vdb_flat_index* ix, int on) {
 int vdb_flat_set_shadow(vdb_flat_index* ix, int on) {
     return guarded([&]() -> int {
     if (!ix || on < 0 || on > 1) return fail(VDB_ERR_INVALID_ARGUMENT, "on must be 0 or 1");
+    if (ix->multi) return multi_for_each(ix, [on](vdb_flat_index* c) { return vdb_flat_set_shadow(c, on); });
     std::lock_guard<std::mutex> g(ix->mu);
     if (in_flight(ix)) return refuse_in_flight();
     HIP_TRY(hipSetDevice(ix->device));
@@ -852,6 +874,7 @@ int vdb_flat_set_shadow(vdb_flat_index* ix, int on) {
 int vdb_flat_set_tiers(vdb_flat_index* ix, unsigned flags) {
     return guarded([&]() -> int {
     if (!ix || (flags & ~7u)) return fail(VDB_ERR_INVALID_ARGUMENT, "flags must be a combination of VDB_TIERS_*");
+    if (ix->multi) return multi_for_each(ix, [flags](vdb_flat_index* c) { return vdb_flat_set_tiers(c, flags); });
     std::lock_guard<std::mutex> g(ix->mu);
     ix->tiers = flags;
     return VDB_OK;
@@ -861,8 +884,32 @@ int vdb_flat_set_tiers(vdb_flat_index* ix, unsigned flags) {
 int vdb_flat_set_screen(vdb_flat_index* ix, int mode) {
     return guarded([&]() -> int {
     if (!ix || mode < 0 || mode > 1) return fail(VDB_ERR_INVALID_ARGUMENT, "mode must be 0 (f32 MFMA tier only) or 1 (bf16 screening tier first)");
+    if (ix->multi) return multi_for_each(ix, [mode](vdb_flat_index* c) { return vdb_flat_set_screen(c, mode); });
     std::lock_guard<std::mutex> g(ix->mu);
     ix->screen = mode;
+    return VDB_OK;
+    });
+}
+
+int vdb_flat_create_sharded(int metric, const int* devices, size_t n_devices, vdb_flat_index** out) {
+    return guarded([&]() -> int { return multi_create(metric, devices, n_devices, out); });
+}
+size_t vdb_flat_shards(const vdb_flat_index* ix) { return !ix ? 0 : ix->multi ? multi_shards(ix) : 1; }
+size_t vdb_flat_shard_len(const vdb_flat_index* ix, size_t shard) {
+    return !ix ? 0 : ix->multi ? multi_shard_len(ix, shard) : (shard == 0 ? vdb_flat_len(ix) : 0);
+}
+int vdb_flat_set_exchange(vdb_flat_index* ix, int mode) {
+    return guarded([&]() -> int {
+    if (!ix) return fail(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    if (!ix->multi) return fail(VDB_ERR_INVALID_ARGUMENT, "not a sharded handle");
+    return multi_set_exchange(ix, mode);
+    });
+}
+int vdb_flat_shard_stats(const vdb_flat_index* ix, uint64_t out[8]) {
+    return guarded([&]() -> int {
+    if (!ix || !out) return fail(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ix->multi) return fail(VDB_ERR_INVALID_ARGUMENT, "not a sharded handle");
+    multi_stats(ix, out);
     return VDB_OK;
     });
 }

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <cstdint>
 #include <cstring>
 #include <mutex>
@@ -134,8 +135,11 @@ struct vdb_knobs {
     bool any = false;                     // some knob differs from its default -> last_stats_ex()[15] = 1
 };
 
+struct vdb_multi;                          // vdb_multi.cpp: the shards of a vdb_flat_create_sharded handle
+
 struct vdb_flat_index {
     int metric = 0, device = 0;
+    vdb_multi* multi = nullptr;           // non-null: this handle is the PARENT of a sharded index and owns nothing below but mu / stats
     vdb_knobs kn;
     uint32_t tiers = 0;                   // vdb_flat_set_tiers: VDB_TIERS_* bits (tier hand-over forced; results identical)
     hipStream_t stream = nullptr;
@@ -233,5 +237,26 @@ int refuse_in_flight();
 int search_device(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, const uint64_t* d_idmask,
                   size_t mask_bits, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
                   hipStream_t user_stream);
+
+// ---- vdb_multi.cpp: one index over several GPUs in one process (the parent handle dispatches here)
+int multi_create(int metric, const int* devices, size_t n, vdb_flat_index** out);
+void multi_destroy(vdb_flat_index* P);
+int multi_add(vdb_flat_index* P, uint64_t id, const float* v, size_t dim);
+int multi_add_bulk(vdb_flat_index* P, const uint64_t* ids, uint64_t first_id, const float* rows, size_t n, size_t dim, bool on_device);
+int multi_remove(vdb_flat_index* P, uint64_t id);
+int multi_get_vector(vdb_flat_index* P, uint64_t id, float* out, size_t cap, size_t* dim);
+size_t multi_len(const vdb_flat_index* P);
+size_t multi_dim(const vdb_flat_index* P);
+int multi_reserve(vdb_flat_index* P, size_t rows, size_t dim);
+int multi_for_each(vdb_flat_index* P, const std::function<int(vdb_flat_index*)>& f);
+int multi_search_device(vdb_flat_index* P, const float* d_q, size_t nq, size_t dim, size_t k, const uint64_t* d_mask, size_t mask_bits,
+                        uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts, hipStream_t user_stream);
+int multi_search_host(vdb_flat_index* P, const float* queries, size_t nq, size_t dim, const size_t* ks, size_t k, const uint64_t* id_mask,
+                      size_t mask_bits, size_t kstride, uint64_t* out_ids, float* out_dists, size_t* out_counts);
+int multi_set_exchange(vdb_flat_index* P, int mode);
+size_t multi_shards(const vdb_flat_index* P);
+size_t multi_shard_len(const vdb_flat_index* P, size_t g);
+void multi_stats(const vdb_flat_index* P, uint64_t out[8]);
+inline int refuse_multi(const char* what) { return fail(VDB_ERR_INVALID_ARGUMENT, "%s is not available on a sharded handle (vdb_flat_create_sharded)", what); }
 
 }  // namespace vdbi

@@ -70,11 +70,20 @@ def _u64p(a):
 class GpuFlatIndex(Index):
     """Drop-in for FlatIndex (src/flat_index.rs) backed by the MI355X engine."""
 
-    def __init__(self, metric, device=0, keep_host_copy=True):
+    EXCHANGE_RCCL, EXCHANGE_PEER = 0, 1
+
+    def __init__(self, metric, device=0, keep_host_copy=True, devices=None):
+        """devices=[d0, d1, ...]: ONE index whose rows are sharded over these GPUs inside this process
+        (vdb_flat_create_sharded; queries and outputs live on d0).  Every method below works on it unchanged."""
         self._metric = DistanceMetric(metric)
         self._h = ctypes.c_void_p()
         self._L = _ffi.lib()
-        rc = self._L.vdb_flat_create(int(self._metric), int(device), ctypes.byref(self._h))
+        if devices is not None:
+            devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+            rc = self._L.vdb_flat_create_sharded(int(self._metric), devs, len(devices), ctypes.byref(self._h))
+            device = devices[0] if len(devices) else 0
+        else:
+            rc = self._L.vdb_flat_create(int(self._metric), int(device), ctypes.byref(self._h))
         if rc:
             _raise(rc)
         self._device = int(device)
@@ -360,3 +369,24 @@ class GpuFlatIndex(Index):
 
     def dim(self):
         return int(self._L.vdb_flat_dim(self._h))
+
+    # ---- sharded handles (vdb_flat_create_sharded)
+    def shards(self):
+        return int(self._L.vdb_flat_shards(self._h))
+
+    def shard_len(self, shard):
+        return int(self._L.vdb_flat_shard_len(self._h, int(shard)))
+
+    def set_exchange(self, mode):
+        """EXCHANGE_RCCL (grouped ncclAllGather over in-process communicators) or EXCHANGE_PEER (peer copies into devices[0])."""
+        rc = self._L.vdb_flat_set_exchange(self._h, int(mode))
+        if rc:
+            _raise(rc)
+
+    def shard_stats(self):
+        out = (ctypes.c_uint64 * 8)()
+        rc = self._L.vdb_flat_shard_stats(self._h, out)
+        if rc:
+            _raise(rc)
+        keys = ["exchanges", "shards", "exchange_mode", "rccl_ranks", "host_total_ns", "host_enqueued_ns"]
+        return dict(zip(keys, [int(v) for v in out]))
