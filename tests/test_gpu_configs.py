@@ -24,6 +24,46 @@ def vdb():
     return v
 
 
+def test_c1_flat_10k_x_128_euclid_single_query_at_its_own_shape(vdb):
+    """BASELINE configs[0] = benches/search_bench.rs:18-33: 10,000 x 128 uniform[0,1) rows, Euclidean, k = 10, ONE query
+    [0.5; 128] -- the literal FlatIndex::search drop-in (src/flat_index.rs:52-65), one vdb_flat_search call.  10k rows take the
+    dense-scores path (indexes up to 16384 rows: every row scored by the f32-input MFMA kernel, no filter pass), the only size
+    of BASELINE that does.  Whole result against the oracle, bit for bit; k = 10000 (the full sort the reference performs)
+    through the exact-scan path as well."""
+    import ctypes
+    n, d, k = 10_000, 128, 10
+    rows = np.random.default_rng(0).random((n, d), dtype=np.float32)
+    q = np.full((d,), 0.5, dtype=np.float32)
+    ix = vdb.GpuFlatIndex(vdb.DistanceMetric.Euclidean, keep_host_copy=False)
+    for i in range(0, 64):                                          # Index::add one row at a time, as the bench's setup does...
+        ix.add(i, vdb.Vector(rows[i]))
+    ix.add_bulk(rows[64:], first_id=64)                             # ... the rest in one call
+    L = vdb._ffi.lib()
+    fp = ctypes.POINTER(ctypes.c_float)
+    out_i, out_d, out_c = np.zeros(k, dtype=np.uint64), np.zeros(k, dtype=np.float32), ctypes.c_size_t()
+    rc = L.vdb_flat_search(ix._h, q.ctypes.data_as(fp), d, k, out_i.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), out_d.ctypes.data_as(fp),
+                           ctypes.byref(out_c))
+    assert rc == 0, vdb._ffi.last_error()
+    oi, od = oracle.flat_search(0, rows, q, k)
+    assert out_c.value == k and np.array_equal(out_i, oi) and np.array_equal(out_d.view(np.uint32), od.view(np.uint32))
+    st = ix.last_stats()
+    assert st["bf16_screen"] == 0 and st["sample_rows"] == n and st["rows_scanned"] == 0 and st["exact_queries"] == 0, st    # dense scores of every row, certified
+    res = ix.search(vdb.Vector(q), k)                               # the trait method of the Python mirror: same call underneath
+    assert [r[0] for r in res] == list(oi) and np.array_equal(np.array([r[1] for r in res], dtype=np.float32).view(np.uint32), od.view(np.uint32))
+    # self-query: distance exactly 0 first (distance.rs:89-93)
+    r0 = ix.search(vdb.Vector(rows[4321]), 1)
+    assert r0[0][0] == 4321 and float(r0[0][1]) == 0.0
+    # the reference sorts ALL rows (flat_index.rs:62): k = len gives the whole ordering
+    gi, gd, gc = ix.search_batch_arrays(q[None, :], n)
+    fi, fd = oracle.flat_search(0, rows, q, n)
+    assert gc[0] == n and np.array_equal(gi[0], fi) and np.array_equal(gd[0].view(np.uint32), fd.view(np.uint32))
+    # the sharded handle at this shape: 3 shards of 3334 / 3333 / 3333 rows, same answer
+    sh = vdb.GpuFlatIndex(vdb.DistanceMetric.Euclidean, devices=[0, 0, 0], keep_host_copy=False)
+    sh.add_bulk(rows)
+    si, sd, sc = sh.search_batch_arrays(q[None, :], k)
+    assert sc[0] == k and np.array_equal(si[0], oi) and np.array_equal(sd[0].view(np.uint32), od.view(np.uint32))
+
+
 def test_c3_one_shard_of_the_10m_job_through_the_shard_group(vdb):
     from vectordb_from_scratch_amd.sharded import ShardGroup, group_search
     n, d, B, k = 1_250_000, 768, 1024, 100

@@ -88,3 +88,11 @@ def test_batch_endpoint_plumbing_over_a_fake_index():
     assert m["total_inserts"] == 30 and m["total_queries"] == 2                   # ONE sample per successful batch (routes.rs:365-369)
     assert m["p50_query_latency_us"] >= 0 and set(m) == {"total_queries", "total_inserts", "total_deletes", "avg_query_latency_us",
                                                           "p50_query_latency_us", "p95_query_latency_us", "p99_query_latency_us"}
+    # `k` is a usize in the reference (routes.rs:334-338) -- a negative, fractional or non-numeric k is a 422, not a
+    # 500; a huge k is clamped to the store length before anything is sized by it (Index::search truncates, flat_index.rs:63)
+    for bad in (-1, 2.5, "3", True):
+        r = client.post("/search/batch", json={"queries": [{"vector": [3.2, 0.0], "k": bad}]})
+        assert r.status_code == 422, (bad, r.status_code)
+    r = client.post("/search/batch", json={"queries": [{"vector": [3.2, 0.0], "k": 10**12}]})
+    assert r.status_code == 200 and len(r.json()[0]) == 30
+    assert client.get("/metrics").json()["total_queries"] == 3

@@ -428,8 +428,16 @@ int vdb_flat_search_batch_device_submit(vdb_flat_index* ix, const float* d_queri
     int slot = !ix->wsv[0].busy ? 0 : (!ix->wsv[1].busy ? 1 : -1);
     if (slot < 0) return fail(VDB_ERR_INVALID_ARGUMENT, "two searches are already in flight on this handle");
     ix->cur = &ix->wsv[slot];
-    int rc = search_part1(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts, (hipStream_t)stream);
-    if (rc) { ix->cur->ctx.pending = false; ix->cur = &ix->wsv[0]; return rc; }
+    // (an exception must not leave ix->cur pointing at the ticket's workspace)
+    int rc = guarded([&]() -> int { return search_part1(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts, (hipStream_t)stream); });
+    if (rc) {
+        // part 1 may have failed AFTER kernels were enqueued (a later allocation, a launch error): they could still write the
+        // caller's buffers after this return -- wait for them, as _begin does
+        hipStream_t s = stream ? (hipStream_t)stream : ix->cur->stream;
+        if (s) (void)hipStreamSynchronize(s);
+        if (ix->wsv[slot ^ 1].stream && !ix->wsv[slot ^ 1].busy) (void)hipStreamSynchronize(ix->wsv[slot ^ 1].stream);   // alternating passes of a large batch
+        ix->cur->ctx.pending = false; ix->cur = &ix->wsv[0]; return rc;
+    }
     ix->cur->busy = true;                       // (a search part 1 answered completely has pending = false: wait() returns at once)
     ix->cur = &ix->wsv[0];
     *ticket = slot;
@@ -446,7 +454,9 @@ int vdb_flat_search_batch_device_wait(vdb_flat_index* ix, int ticket) {
     int rc = set_device(ix);
     if (rc) return rc;
     ix->cur = &ix->wsv[ticket];
-    rc = search_part2(ix, nullptr);
+    // (whatever part 2 does -- an exception from its host vectors included -- the ticket is retired: a workspace left busy
+    // would refuse add / remove / flush on the handle for ever)
+    rc = guarded([&]() -> int { return search_part2(ix, nullptr); });
     publish_stats(ix);
     ix->cur->ctx.pending = false;
     ix->cur->busy = false;

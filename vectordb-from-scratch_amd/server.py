@@ -166,23 +166,41 @@ def create_app(state):
                 state.metrics.record_insert()
         return JSONResponse({"inserted": len(items)}, status_code=201)
 
+    def parse_k(v):
+        # routes.rs:334-338: `k: Option<usize>`, default 10 -- serde rejects a negative, fractional or non-numeric k (422)
+        if v is None:
+            return 10
+        if isinstance(v, bool) or not isinstance(v, int) or v < 0:
+            raise ValueError(f"k must be a non-negative integer, got {v!r}")
+        return v
+
+    def run_batch(queries, flt, prefilter):
+        with state.store_lock.read():
+            # Index::search returns at most len results (flat_index.rs:63): clamp before any buffer is sized by k
+            n = state.store.len()
+            queries = [(q, min(k, n)) for q, k in queries]
+            if flt is not None and prefilter:
+                return state.store.search_batch_prefiltered(queries, flt)       # extension: device bitmask before top-k
+            if flt is not None:
+                return state.store.search_batch_with_filter(queries, flt)       # routes.rs:352-353
+            return state.store.search_batch(queries)                            # routes.rs:354-355: ONE index call
+
     async def batch_search(request):                      # routes.rs:330-385
+        from starlette.concurrency import run_in_threadpool
         try:
             req = await request.json()
-            queries = [(Vector(q["vector"]), int(q["k"]) if q.get("k") is not None else 10) for q in req["queries"]]
+            queries = [(Vector(q["vector"]), parse_k(q.get("k"))) for q in req["queries"]]
             flt = filter_from_json(req["filter"]) if req.get("filter") is not None else None
         except (KeyError, TypeError, ValueError) as e:
             return bad_request(e, 422)
         start = time.perf_counter()
         try:
-            with state.store_lock.read():
-                if flt is not None and req.get("prefilter"):
-                    all_results = state.store.search_batch_prefiltered(queries, flt)       # extension: device bitmask before top-k
-                elif flt is not None:
-                    all_results = state.store.search_batch_with_filter(queries, flt)       # routes.rs:352-353
-                else:
-                    all_results = state.store.search_batch(queries)                        # routes.rs:354-355: ONE index call
+            # the blocking GPU call runs off the event loop, so that the shared mode of the RwLock (routes.rs:342) really admits
+            # concurrent searches
+            all_results = await run_in_threadpool(run_batch, queries, flt, bool(req.get("prefilter")))
         except VectorDbError as e:
+            return bad_request(e)
+        except (ValueError, OverflowError, MemoryError) as e:
             return bad_request(e)
         elapsed = time.perf_counter() - start
         with state.metrics_lock.write():

@@ -92,6 +92,7 @@ class _Column:
             self.codes = new
 
     def code(self, value, create=False):
+        value = str(value)                               # Metadata is HashMap<String, String> (storage.rs:19-22): one encoding for set and set_range
         c = self.code_of.get(value)
         if c is None and create:
             c = self.code_of[value] = len(self.values)
@@ -155,6 +156,8 @@ class VectorStore:
         else:
             self._dimension = dim
         old = self._id_to_internal.get(id)
+        if old is None:
+            old = self._bulk_internal(id)                # an id that names a bulk-attached row: the insert replaces that row
         if old is not None:
             self._index.remove(old)
             self._metadata.pop(old, None)
@@ -178,6 +181,8 @@ class VectorStore:
     def delete(self, id):                            # storage.rs:175-192
         internal = self._id_to_internal.pop(id, None)
         if internal is None:
+            internal = self._bulk_internal(id)
+        if internal is None:
             raise VectorNotFound(id)
         v = self._index.get_vector(internal)
         if v is None:
@@ -189,17 +194,27 @@ class VectorStore:
         return v
 
     # ---- reads
-    def get(self, id):                               # storage.rs:195-198
+    def _internal_of(self, id):
+        """String id -> internal id, for inserted rows and for bulk-attached rows alike (None: unknown)."""
         internal = self._id_to_internal.get(id)
+        return internal if internal is not None else self._bulk_internal(id)
+
+    def _metadata_of(self, internal):
+        """The row's Metadata (storage.rs:90): the stored object of an inserted row, or the columns of a bulk-attached row
+        materialised on demand."""
+        meta = self._metadata.get(internal)
+        if meta is None and self._bulk_id(internal) is not None:
+            meta = Metadata({k: c.values[c.codes[internal]] for k, c in self._cols.items()
+                             if internal < c.codes.size and c.codes[internal] >= 0})
+        return meta
+
+    def get(self, id):                               # storage.rs:195-198
+        internal = self._internal_of(id)
         return None if internal is None else self._index.get_vector(internal)
 
     def get_metadata(self, id):                      # storage.rs:201-204
-        internal = self._id_to_internal.get(id)
-        if internal is None and self._bulk and str(id).isdigit() and self._bulk_id(int(id)) == str(id):
-            internal = int(id)
-            return Metadata({k: c.values[c.codes[internal]] for k, c in self._cols.items()
-                             if internal < c.codes.size and c.codes[internal] >= 0})
-        return None if internal is None else self._metadata.get(internal)
+        internal = self._internal_of(id)
+        return None if internal is None else self._metadata_of(internal)
 
     def len(self):
         return self._index.len()
@@ -220,7 +235,11 @@ class VectorStore:
         return self._index
 
     def list_ids(self):
-        return list(self._id_to_internal)
+        out = list(self._id_to_internal)
+        for start, n, ids, _ in self._bulk:
+            live = np.nonzero(self._present[start:start + n])[0]
+            out.extend(str(start + int(j)) if ids is None else ids[int(j)] for j in live)
+        return out
 
     def _mark_present(self, internal, on):
         if internal >= self._present.size:
@@ -238,24 +257,50 @@ class VectorStore:
         start = self._next_id
         if ids is not None and len(ids) != n:
             raise ValueError("ids must have n entries")
+        # one id, one row: a bulk id that names a row already in the store would make upsert / delete act on the wrong one
+        new_ids = [str(i) for i in ids] if ids is not None else None
+        if new_ids is not None:
+            if len(set(new_ids)) != n:
+                raise ValueError("bulk ids must be distinct")
+            clash = next((i for i in new_ids if self._internal_of(i) is not None), None)
+        else:
+            clash = next((i for i in self._id_to_internal if i.isdigit() and str(int(i)) == i and start <= int(i) < start + n), None)
+            if clash is None:
+                clash = next((i for s0, m, other, _ in self._bulk if other is not None
+                              for i in other if i.isdigit() and str(int(i)) == i and start <= int(i) < start + n), None)
+        if clash is not None:
+            raise ValueError(f"bulk id {clash!r} is already in use")
         for key, values in columns.items():
             if len(values) != n:
                 raise ValueError(f"column {key!r} must have n entries")
             self._cols.setdefault(key, _Column()).set_range(start, values)
         self._mark_present(start + n - 1, False)                 # grow once
         self._present[start:start + n] = True
-        self._bulk.append((start, n, None if ids is None else list(ids)))
+        self._bulk.append((start, n, new_ids, None if new_ids is None else {sid: start + j for j, sid in enumerate(new_ids)}))
         self._next_id += n
         if self._dimension is None and hasattr(self._index, "dim"):
             self._dimension = self._index.dim() or None
         return start
 
     def _bulk_id(self, internal):
-        for start, n, ids in self._bulk:
+        for start, n, ids, _ in self._bulk:
             if start <= internal < start + n:
                 if not self._present[internal]:
                     return None
                 return str(internal) if ids is None else ids[internal - start]
+        return None
+
+    def _bulk_internal(self, id):
+        """Internal id of a LIVE bulk-attached row named `id` (None: no such row)."""
+        id = str(id)
+        for start, n, ids, lut in self._bulk:
+            if ids is None:
+                if id.isdigit() and str(int(id)) == id and start <= int(id) < start + n and self._present[int(id)]:
+                    return int(id)
+            else:
+                internal = lut.get(id)
+                if internal is not None and self._present[internal]:
+                    return internal
         return None
 
     def _check_dim(self, query):
@@ -283,7 +328,9 @@ class VectorStore:
         out = []
         for internal, dist in index_results:
             sid = self._internal_to_id.get(internal)
-            meta = self._metadata.get(internal)
+            if sid is None and self._bulk:
+                sid = self._bulk_id(internal)             # rows registered by attach_bulk_metadata live in the columns only
+            meta = self._metadata_of(internal) if sid is not None else None
             if sid is None or meta is None:
                 continue
             if flt.matches(meta):
@@ -327,7 +374,7 @@ class VectorStore:
             codes = col.view(n)
             if flt.op == "exists":
                 return codes >= 0
-            c = col.code(flt.value)
+            c = col.code(flt.value) if flt.value is not None else None
             if flt.op == "eq":
                 return (codes == c) if c is not None else np.zeros(n, dtype=bool)
             return (codes != c) if c is not None else np.ones(n, dtype=bool)      # Ne: a missing field matches (storage.rs:65)
