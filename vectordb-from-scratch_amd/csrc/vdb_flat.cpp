@@ -381,7 +381,11 @@ int vdb_flat_search_batch_device_begin(vdb_flat_index* ix, const float* d_querie
     int rc = guarded([&]() -> int { return search_part1(ix, d_queries, nq, dim, k, d_id_mask, mask_bits, d_out_ids, d_out_dists, d_out_counts, (hipStream_t)stream, true); });
     if (rc == VDB_OK && d_code) {
         hipStream_t s = stream ? (hipStream_t)stream : ix->stream;
-        if (ix->cur->ctx.pending) vdb::launch_write_code(ix->cur->w_flags.p, d_code, s);
+        // (a forced hand-over to the slower tiers -- vdb_flat_set_tiers, tests -- rewrites the outputs in _finish whatever the
+        // first tier certified: the word says "pending" then, so that a caller exchanging partial results exchanges again)
+        if (ix->cur->ctx.pending && (ix->tiers & (VDB_TIERS_FORCE_EXACT | VDB_TIERS_FORCE_F32))) {
+            if (hipMemsetD32Async((hipDeviceptr_t)d_code, VDB_PENDING_HOST, 1, s) != hipSuccess) rc = fail(VDB_ERR_DEVICE, "hipMemsetD32Async failed");
+        } else if (ix->cur->ctx.pending) vdb::launch_write_code(ix->cur->w_flags.p, d_code, s);
         else if (hipMemsetAsync(d_code, 0, 4, s) != hipSuccess) rc = fail(VDB_ERR_DEVICE, "hipMemsetAsync failed");
     }
     if (rc == VDB_OK && !stream) {

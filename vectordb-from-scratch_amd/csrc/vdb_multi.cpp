@@ -259,6 +259,10 @@ int multi_create(int metric, const int* devices, size_t n, vdb_flat_index** out)
     if (!devices || n == 0) return fail(VDB_ERR_INVALID_ARGUMENT, "at least one device is required");
     if (n > 64) return fail(VDB_ERR_INVALID_ARGUMENT, "at most 64 shards");
     if (metric < 0 || metric > 2) return fail(VDB_ERR_INVALID_ARGUMENT, "unknown metric %d", metric);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VDB_ERR_DEVICE, "no HIP device available: this engine has no CPU path");
+    for (size_t g = 0; g < n; ++g)
+        if (devices[g] < 0 || devices[g] >= ndev) return fail(VDB_ERR_INVALID_ARGUMENT, "device %d out of range (%d)", devices[g], ndev);
     auto* P = new vdb_flat_index();
     auto* M = new vdb_multi();
     P->multi = M;
@@ -327,6 +331,7 @@ void multi_destroy(vdb_flat_index* P) {
         delete M;
     }
     delete P;
+    (void)hipGetLastError();                   // teardown is best effort: leave no stale error behind for the thread's next call
 }
 
 // ------------------------------------------------------------------ mutation and inspection
