@@ -405,9 +405,9 @@ def main():
     if args.screen and not args.no_f32_tier:
         index.set_screen(0)
         n_f32 = max(3, min(args.steps, 10))
-        el32, o32 = timed(step, 2, n_f32)
+        k32 = kernel_ms_of(index, step, 3, local_rows)          # (the event-synchronised launches first: the leg ends on its
+        el32, o32 = timed(step, 2, n_f32)                       # continuous part, ~40 ms of dense GPU work right before the headline)
         o32 = tuple(t.clone() for t in o32)
-        k32 = kernel_ms_of(index, step, 3, local_rows)
         f32_raw = (el32, n_f32, o32, k32)
         index.set_screen(1)
 
