@@ -264,6 +264,7 @@ def main():
     ap.add_argument("--lean", action="store_true", help="headline only: every side measurement off (profiling runs)")
     ap.add_argument("--data", default="uniform", choices=["uniform", "gauss"], help="distribution of the HEADLINE index")
     ap.add_argument("--screen", type=int, default=1, help="1: bf16 screening tier first (default); 0: f32 MFMA tier only")
+    ap.add_argument("--no-wide", action="store_true", help="batches above 256 queries: 256-query passes instead of the 512-query filter kernel (A/B)")
     ap.add_argument("--dry-launch", action="store_true", help="print this rank's RANK / WORLD_SIZE / LOCAL_RANK as a JSON line and exit (no GPU is touched)")
     args = ap.parse_args()
     if args.lean:
@@ -319,6 +320,8 @@ def main():
 
     index = build_index(vdb, metric, lo, hi, n_rows, dim, device, local_rank)
     index.set_screen(args.screen)
+    if args.no_wide:
+        index.set_wide(False)
     queries = gen_queries(B, dim, device)
 
     # ---- c4: the metadata filter, compiled from string metadata to the device bitmask (timed: it is part of an honest C4)

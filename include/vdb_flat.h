@@ -258,6 +258,13 @@ int vdb_flat_last_stats_ex(const vdb_flat_index *h, uint64_t *out, size_t n);
  */
 int vdb_flat_set_screen(vdb_flat_index *h, int mode);
 
+/* Batches above 256 queries (VectorStore::search_batch takes any number, storage.rs:302-310; BASELINE config 3: 1024):
+ *  1 (default): the screening pass serves 512 queries per fetch of the rows (128 rows x 512 queries per workgroup), so a batch
+ *     of B queries reads the database ceil(B / 512) times;
+ *  0: 256 queries per fetch (the kernel of batches up to 256), ceil(B / 256) reads.
+ * No reference counterpart; results are identical either way, bit for bit. */
+int vdb_flat_set_wide(vdb_flat_index *h, int on);
+
 /*
  * Opt-in bf16 SHADOW of the rows for the screening pass (no reference counterpart; results are identical with and without
  * it).  on = 1: the index keeps, next to the f32 rows, their bf16 roundings (+50 % device memory: 2 bytes per element on top

@@ -403,3 +403,72 @@ def test_nan_and_wild_norms_under_the_min_test_of_the_epilogue(vdb):
         a3, st3, b3 = both_tiers(ix2, q, k)
         assert same(a3, b3)
         check_oracle(metric, base, q, k, a3, [0])
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("n,d,nq,k", [
+    (70001, 64, 257, 10),        # one wide pass whose second block holds ONE query; ragged last 128-row tile
+    (140000, 96, 512, 10),       # exactly one wide pass
+    (200000, 48, 700, 50),       # a wide pass (512) + an ordinary pass (188 queries), k' = 512
+    (131072, 768, 1024, 100),    # BASELINE config 3's batch and k at the headline dimension: two wide passes
+    (90000, 100, 300, 16),       # dimension padded 100 -> 128: the shadow rows are not usable, the wide kernel is
+])
+def test_wide_filter_pass_equals_the_256_query_passes(vdb, metric, n, d, nq, k):
+    """Batches above 256 queries: the 128-row x 512-query kernel (kernels_fused_bf16w.hip) serves two 256-query blocks per
+    fetch of the rows.  Same thresholds, same pools' content, same results, bit for bit, as the 256-query passes and as the
+    f32 tier; the rows are scanned ceil(B / 512) times instead of ceil(B / 256)."""
+    rng = np.random.default_rng(5 * n + d + nq + metric)
+    rows = rng.random((n, d), dtype=np.float32)
+    q = rng.random((nq, d), dtype=np.float32)
+    ix = make_index(vdb, metric, rows)
+    for i in range(0, n, 997):                                    # tombstones in every tile neighbourhood
+        ix.remove(i)
+    live = np.ones(n, dtype=np.uint8); live[::997] = 0
+    ix.set_wide(True)
+    a = ix.search_batch_arrays(q, k)
+    st_w = ix.last_stats()
+    thr_w = ix.debug_last_thresholds(nq)
+    ix.set_wide(False)
+    b = ix.search_batch_arrays(q, k)
+    st_n = ix.last_stats()
+    thr_n = ix.debug_last_thresholds(nq)
+    ix.set_screen(0)
+    c = ix.search_batch_arrays(q, k)
+    ix.set_screen(1); ix.set_wide(True)
+    assert same(a, b) and same(a, c)
+    assert np.array_equal(thr_w.view(np.uint32), thr_n.view(np.uint32))
+    wide_used = not (shadow_on() and ((d + 31) // 32) % 2 == 0)    # the shadow rows' kernel has the one shape
+    assert st_n["rows_scanned"] == -(-nq // 256) * n, st_n
+    assert st_w["rows_scanned"] == (-(-nq // 512) * n if wide_used else st_n["rows_scanned"]), st_w
+    for key in ("mfma_queries", "exact_queries", "pool_overflows", "uncertified", "f32_tier_queries", "rethreshold_queries"):
+        assert st_w[key] == st_n[key], (key, st_w, st_n)
+    assert st_w["pool_overflows"] == 0 and st_w["exact_queries"] == 0, st_w
+    check_oracle(metric, rows, q, k, a, sorted({0, 255, 256, nq // 2, nq - 1}), live=live)
+
+
+def test_wide_filter_pass_with_prefilter_mask_and_clustered_rows(vdb):
+    """The wide kernel's rare path: an id mask at 3 % selectivity and a cluster stored contiguously (its keys land in ONE
+    workgroup's two sub-pools per query -- this shape has two per workgroup where the 256-query kernel has four)."""
+    rng = np.random.default_rng(77)
+    n, d, nq, k = 120000, 64, 600, 10
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    centre = rng.standard_normal(d).astype(np.float32)
+    rows[50000:50400] = centre + 0.05 * rng.standard_normal((400, d)).astype(np.float32)      # 400 neighbours in 4 consecutive tiles
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    q[::7] = centre + 0.05 * rng.standard_normal((len(q[::7]), d)).astype(np.float32)
+    ix = make_index(vdb, 0, rows)
+    a = ix.search_batch_arrays(q, k)
+    st = ix.last_stats()
+    ix.set_wide(False)
+    b = ix.search_batch_arrays(q, k)
+    assert same(a, b) and st["exact_queries"] == ix.last_stats()["exact_queries"]
+    ix.set_wide(True)
+    check_oracle(0, rows, q, k, a, [0, 7, 300, 301, 599])
+    live = (rng.random(n) < 0.03).astype(np.uint8)
+    mask = np.packbits(live, bitorder="little")
+    mask = np.concatenate([mask, np.zeros((-len(mask)) % 8, dtype=np.uint8)]).view(np.uint64)
+    m = ix.search_batch_arrays(q, k, id_mask=mask, mask_bits=n)
+    ix.set_wide(False)
+    m2 = ix.search_batch_arrays(q, k, id_mask=mask, mask_bits=n)
+    assert same(m, m2)
+    check_oracle(0, rows, q, k, m, [0, 256, 511, 599], live=live)

@@ -15,7 +15,7 @@ SYMBOLS = [
     "vdb_flat_create", "vdb_flat_destroy", "vdb_flat_create_sharded", "vdb_flat_shards", "vdb_flat_shard_len", "vdb_flat_set_exchange", "vdb_flat_shard_stats", "vdb_flat_add", "vdb_flat_add_bulk", "vdb_flat_add_bulk_device",
     "vdb_flat_load_vector_file", "vdb_flat_remove", "vdb_flat_get_vector", "vdb_flat_len", "vdb_flat_metric", "vdb_flat_dim",
     "vdb_flat_reserve", "vdb_flat_flush", "vdb_flat_search", "vdb_flat_search_batch",
-    "vdb_flat_search_batch_device", "vdb_flat_search_batch_device_begin", "vdb_flat_search_batch_device_finish", "vdb_flat_search_batch_device_submit", "vdb_flat_search_batch_device_wait", "vdb_flat_distances_batch", "vdb_merge_topk_device", "vdb_merge_topk_packed_device", "vdb_flat_set_profile", "vdb_flat_last_stats", "vdb_flat_last_stats_ex", "vdb_flat_set_screen", "vdb_flat_set_shadow", "vdb_flat_set_sample_cache", "vdb_flat_set_tiers", "vdb_flat_debug_screen_scores", "vdb_flat_debug_rows", "vdb_flat_debug_row_info", "vdb_flat_debug_last_thresholds", "vdb_flat_debug_cert_probe", "vdb_last_error",
+    "vdb_flat_search_batch_device", "vdb_flat_search_batch_device_begin", "vdb_flat_search_batch_device_finish", "vdb_flat_search_batch_device_submit", "vdb_flat_search_batch_device_wait", "vdb_flat_distances_batch", "vdb_merge_topk_device", "vdb_merge_topk_packed_device", "vdb_flat_set_profile", "vdb_flat_last_stats", "vdb_flat_last_stats_ex", "vdb_flat_set_screen", "vdb_flat_set_wide", "vdb_flat_set_shadow", "vdb_flat_set_sample_cache", "vdb_flat_set_tiers", "vdb_flat_debug_screen_scores", "vdb_flat_debug_rows", "vdb_flat_debug_row_info", "vdb_flat_debug_last_thresholds", "vdb_flat_debug_cert_probe", "vdb_last_error",
     "vdb_abi_version", "vdb_build_arch",
     # include/vdb_hnsw.h
     "vdb_hnsw_create", "vdb_hnsw_destroy", "vdb_hnsw_add", "vdb_hnsw_add_bulk", "vdb_hnsw_remove", "vdb_hnsw_search_batch",
@@ -102,6 +102,7 @@ def lib():
     L.vdb_flat_last_stats.argtypes = [vp, u64p]
     L.vdb_flat_last_stats_ex.argtypes = [vp, u64p, sz]
     L.vdb_flat_set_screen.argtypes = [vp, c.c_int]
+    L.vdb_flat_set_wide.argtypes = [vp, c.c_int]
     L.vdb_flat_set_tiers.argtypes = [vp, c.c_uint]
     L.vdb_flat_set_shadow.argtypes = [vp, c.c_int]
     L.vdb_flat_set_sample_cache.argtypes = [vp, c.c_int]

@@ -189,6 +189,9 @@ struct FusedBf16Params {
     const float* thr;                                  // [256]
     uint64_t* pool; uint32_t* pool_cnt; uint32_t capl;
     uint32_t n_wg;                                     // row ranges = grid.x
+    // the WIDE filter kernel (kernels_fused_bf16w.hip) serves two consecutive 256-query blocks per launch: qb / thr / qg cover
+    // 512 queries, block b's pools start at pool + b * pool_block_stride (keys) and pool_cnt + b * cnt_block_stride
+    size_t pool_block_stride, cnt_block_stride;
     // sample mode: n_sample = 2^sample_shift <= n_rows, sample j -> row (j*n_rows) >> sample_shift; per query and
     // group of 64 sample rows the smallest key
     uint32_t n_sample, sample_shift, sample_block; uint64_t* minkeys; uint32_t minkey_stride;   // minkeys[q*minkey_stride + group]
@@ -199,6 +202,8 @@ void launch_fused_bf16(const FusedBf16Params& p, hipStream_t s);      // unpipel
 #endif
 void launch_sample_bf16(const FusedBf16Params& p, uint32_t n_cu, hipStream_t s);
 void launch_fused_bf16p(const FusedBf16Params& p, hipStream_t s);     // kernels_fused_bf16p.hip: the filter pass, software-pipelined (default)
+void launch_fused_bf16w(const FusedBf16Params& p, hipStream_t s);     // kernels_fused_bf16w.hip: the WIDE filter pass, 128 rows x 512 queries per workgroup (batches above 256 queries)
+uint32_t fused_bf16w_tile_rows();
 // With every row norm and query norm in [2^-40, 2^40] (zero allowed) no accumulator can overflow and no alpha / beta is
 // non-finite, so fma(acc, alpha, beta) is never NaN -- the filter epilogues may then test the MINIMUM of four scores against the
 // threshold (v_min_f32 drops a NaN operand; a NaN score must pass the filter, flat_index.rs:62).  Otherwise they add a NaN

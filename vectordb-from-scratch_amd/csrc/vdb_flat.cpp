@@ -905,6 +905,16 @@ int vdb_flat_set_screen(vdb_flat_index* ix, int mode) {
     });
 }
 
+int vdb_flat_set_wide(vdb_flat_index* ix, int on) {
+    return guarded([&]() -> int {
+    if (!ix || on < 0 || on > 1) return fail(VDB_ERR_INVALID_ARGUMENT, "on must be 0 or 1");
+    if (ix->multi) return multi_for_each(ix, [on](vdb_flat_index* c) { return vdb_flat_set_wide(c, on); });
+    std::lock_guard<std::mutex> g(ix->mu);
+    ix->wide = on != 0;
+    return VDB_OK;
+    });
+}
+
 int vdb_flat_create_sharded(int metric, const int* devices, size_t n_devices, vdb_flat_index** out) {
     return guarded([&]() -> int { return multi_create(metric, devices, n_devices, out); });
 }

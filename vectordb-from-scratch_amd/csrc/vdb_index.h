@@ -187,6 +187,7 @@ struct vdb_flat_index {
     hipEvent_t ev_pass[2] = {nullptr, nullptr};             // fork / join of the alternating passes of a large batch (pass_bf16)
     hipEvent_t ev_order = nullptr;                          // orders the handle's stream before the null stream (search_batch_device_begin)
     int screen = 1;                                         // 1: bf16 screening tier first (default), 0: f32 MFMA tier only
+    bool wide = true;                                       // batches above 256 queries: the 512-query filter kernel (vdb_flat_set_wide)
     uint64_t stats[16] = {0};                               // counters of the last COMPLETED search (copied from its context)
     bool profile = false; hipEvent_t ev0 = nullptr, ev1 = nullptr;
 

@@ -176,13 +176,23 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
     // counts and keys, never empty slots, so the capacity costs address space only (0.5 GB of workspace at 1M rows).
     const uint32_t capl = 256;
     const uint32_t n_wg = std::min<uint32_t>((uint32_t)ix->n_cu, (n + vdb::fused_bf16_tile_rows() - 1) / vdb::fused_bf16_tile_rows());
-    const uint32_t n_sub = vdb::fused_bf16_subpools_per_query(n_wg);
-    // A batch above 256 queries takes several passes (BASELINE config 3: four).  They are independent, so they ALTERNATE between
+    // Batches above 256 queries: the WIDE filter kernel (kernels_fused_bf16w.hip, 128 rows x 512 queries per workgroup) serves
+    // two 256-query blocks per fetch of the rows -- BASELINE config 3 (B = 1024) reads its shard twice per batch instead of
+    // four times.  Not over the opt-in bf16 shadow rows (their kernel has the one shape); vdb_flat_set_wide(h, 0) turns it off.
+    const bool use_wide = ix->wide && nq > SUPER && !shadow_usable(ix)
+#ifdef VDB_DIAG
+                          && ix->kn.fused_pipe
+#endif
+        ;
+    const uint32_t n_wg_w = std::min<uint32_t>((uint32_t)ix->n_cu, (n + vdb::fused_bf16w_tile_rows() - 1) / vdb::fused_bf16w_tile_rows());
+    const uint32_t n_sub = vdb::fused_bf16_subpools_per_query(std::max(n_wg, use_wide ? n_wg_w : 0u));   // (both kernels write the 4-sub-pool layout)
+    const size_t pool_block = (size_t)SUPER * n_sub * capl, cnt_block = (size_t)SUPER * n_sub;
+    // A batch above 256 queries takes several passes.  They are independent, so they ALTERNATE between
     // this context and the handle's other workspace and stream when that one is idle: the latency-bound tail of pass i (its
     // slowest re-rank workgroups, a few CUs) then runs beside the head of pass i+1 instead of in front of it.  The per-query
     // arrays (queries, thresholds, flags, outputs) are indexed by q0 and shared; only the pass-local buffers are doubled.
     Workspace* alt = nullptr;
-    if (allow_alt && nq > SUPER && !ix->profile && !ix->kn.rr_depth) {
+    if (allow_alt && nq > (use_wide ? 2 * SUPER : SUPER) && !ix->profile && !ix->kn.rr_depth) {
         Workspace* o = (ix->cur == &ix->wsv[0]) ? &ix->wsv[1] : &ix->wsv[0];
         if (!o->busy) alt = o;
     }
@@ -193,8 +203,8 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         if ((rc = w->w_dense.ensure((size_t)SUPER * M))) return rc;
         if ((rc = w->w_cand.ensure((size_t)SUPER * kp))) return rc;
         if ((rc = w->w_samp.ensure((size_t)SUPER * std::max(kp, KT)))) return rc;
-        if ((rc = w->w_pool.ensure((size_t)SUPER * n_sub * capl))) return rc;
-        if ((rc = w->w_subcnt.ensure((size_t)SUPER * n_sub))) return rc;
+        if ((rc = w->w_pool.ensure((use_wide ? 2 : 1) * pool_block))) return rc;
+        if ((rc = w->w_subcnt.ensure((use_wide ? 2 : 1) * cnt_block))) return rc;
         if ((rc = w->w_cnt.ensure(4 * SUPER + 16))) return rc;
     }
     // the sample pass runs over the compact bf16 copy of the sample rows when the row pitch allows (rebuilt here, before the
@@ -229,35 +239,45 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
     }
     ix->cur->stats[4] = S;
     const float eps = eps_coef(ix);
-    for (uint32_t q0 = 0, pass = 0; q0 < nq; q0 += SUPER, ++pass) {
-        const uint32_t nb = std::min(SUPER, nq - q0);
+    for (uint32_t q0 = 0, pass = 0; q0 < nq; ++pass) {
+        const bool wide = use_wide && nq - q0 > SUPER;            // two 256-query blocks share this pass's fetch of the rows
+        const uint32_t n_blocks = wide ? 2u : 1u;
         Workspace* const W = Wv[pass & 1];                        // pass-local buffers
         const hipStream_t s = Sv[pass & 1];                       // (shadows the caller's stream inside the loop)
         uint32_t* d_cnt_a = W->w_cnt.p;
         uint32_t* d_cand_cnt = W->w_cnt.p + 2 * SUPER;
         vdb::FusedBf16Params fp{};
-        fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n; fp.qb = ix->cur->w_qb.p + (size_t)q0 * ld;
+        fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n;
         fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
-        fp.margin = ix->d_margin; fp.qg = ix->d_margin ? ix->cur->w_qg.p + q0 : nullptr;
-        fp.thr = ix->cur->w_thr.p + q0; fp.pool = W->w_pool.p; fp.pool_cnt = W->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
+        fp.margin = ix->d_margin;
+        fp.pool = W->w_pool.p; fp.pool_cnt = W->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
         fp.scalars = ix->d_scalars; fp.qmax_bits = d_status + 2;
         fp.ablate = ix->kn.bf16_ablate;
         fp.n_sample = S; fp.sample_shift = pl.shift;
         fp.sample_block = ix->kn.sample_block ? (n / (S / 256u)) : 0u; fp.minkeys = W->w_dense.p; fp.minkey_stride = M;
-        if (sample_copy) {
-            vdb::FusedBf16Params sp16 = fp;
-            sp16.rows16 = ix->d_sample16;
-            vdb::launch_sample_s16(sp16, s);
-        } else vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);
+        // ---- thresholds of the pass's blocks: sample pass + threshold select per 256 queries
+        for (uint32_t b = 0; b < n_blocks; ++b) {
+            const uint32_t qb0 = q0 + b * SUPER, nb = std::min(SUPER, nq - qb0);
+            fp.qb = ix->cur->w_qb.p + (size_t)qb0 * ld; fp.qg = ix->d_margin ? ix->cur->w_qg.p + qb0 : nullptr; fp.thr = ix->cur->w_thr.p + qb0;
+            if (sample_copy) {
+                vdb::FusedBf16Params sp16 = fp;
+                sp16.rows16 = ix->d_sample16;
+                vdb::launch_sample_s16(sp16, s);
+            } else vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);
 
-        vdb::SelectParams sp{};
-        sp.keys = W->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = KT;
-        sp.out_stride = KT; sp.out_keys = W->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->cur->w_thr.p + q0; sp.ovf = nullptr;
-        if (ix->d_margin) { sp.shift_g = ix->cur->w_qg.p + q0; sp.shift_m_bits = ix->d_scalars + 4; }   // plain-score sample -> lower-bound units
-        vdb::launch_thr_select(sp, nb, s);
-
+            vdb::SelectParams sp{};
+            sp.keys = W->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = KT;
+            sp.out_stride = KT; sp.out_keys = W->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->cur->w_thr.p + qb0; sp.ovf = nullptr;
+            if (ix->d_margin) { sp.shift_g = ix->cur->w_qg.p + qb0; sp.shift_m_bits = ix->d_scalars + 4; }   // plain-score sample -> lower-bound units
+            vdb::launch_thr_select(sp, nb, s);
+        }
+        // ---- ONE pass over the rows for all of them
+        fp.qb = ix->cur->w_qb.p + (size_t)q0 * ld; fp.qg = ix->d_margin ? ix->cur->w_qg.p + q0 : nullptr; fp.thr = ix->cur->w_thr.p + q0;
         if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
-        launch_filter_pass(ix, fp, s);
+        if (wide) {
+            fp.n_wg = n_wg_w; fp.pool_block_stride = pool_block; fp.cnt_block_stride = cnt_block;
+            vdb::launch_fused_bf16w(fp, s);
+        } else launch_filter_pass(ix, fp, s);
         if (ix->profile) {
             HIP_TRY(hipEventRecord(ix->ev1, s));
             HIP_TRY(hipEventSynchronize(ix->ev1));
@@ -270,57 +290,64 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         // slower tiers, and the extra milliseconds of f32 MFMA work change the clock the NEXT timed launch runs at (ablation
         // arms with broken results read 10-25 us low for that reason alone).  So the ablated launch is the timed one, and an
         // unablated launch (untimed) overwrites its pools: every arm of an A/B then runs the same step around the kernel.
-        if (fp.ablate) { fp.ablate = 0; launch_filter_pass(ix, fp, s); ix->cur->stats[3] += n; }
+        if (fp.ablate) {
+            fp.ablate = 0;
+            if (wide) vdb::launch_fused_bf16w(fp, s); else launch_filter_pass(ix, fp, s);
+            ix->cur->stats[3] += n;
+        }
 #endif
         ix->cur->stats[3] += n;
 
-        vdb::SelectParams mp{};
-        mp.keys = W->w_pool.p; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
-        mp.sub_counts = W->w_subcnt.p; mp.n_sub = n_sub; mp.capl = capl; mp.wg_major = 1;
-        mp.kk = kp; mp.out_keys = W->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
-        mp.out_thr = nullptr; mp.ovf = d_ovf + q0; mp.summary = d_status + 1;
-        vdb::launch_select(mp, nb, s);
+        // ---- per block: the smallest pooled keys, then the exact re-rank
+        for (uint32_t b = 0; b < n_blocks; ++b) {
+            const uint32_t qb0 = q0 + b * SUPER, nb = std::min(SUPER, nq - qb0);
+            vdb::SelectParams mp{};
+            mp.keys = W->w_pool.p + (size_t)b * pool_block; mp.stride = 0; mp.counts = nullptr; mp.n_fixed = 0; mp.cap = 0;
+            mp.sub_counts = W->w_subcnt.p + (size_t)b * cnt_block; mp.n_sub = vdb::fused_bf16_subpools_per_query(wide ? n_wg_w : n_wg);
+            mp.capl = capl; mp.wg_major = 1;
+            mp.kk = kp; mp.out_keys = W->w_cand.p; mp.out_stride = kp; mp.out_cnt = d_cand_cnt;
+            mp.out_thr = nullptr; mp.ovf = d_ovf + qb0; mp.summary = d_status + 1;
+            vdb::launch_select(mp, nb, s);
 
-        vdb::RerankParams rp{};
-        rp.rows = ix->d_rows; rp.ld = ld; rp.dim = ix->dim; rp.n_rows = n;
-        rp.qp = ix->cur->w_qp.p + (size_t)q0 * ld; rp.qnorm = ix->cur->w_qnorm.p + q0; rp.nd = ix->d_nd; rp.row_ids = ix->d_row_ids;
-        rp.rowmask = d_rowmask; rp.cand = W->w_cand.p; rp.cand_stride = kp; rp.cand_cnt = d_cand_cnt; rp.kp = kp;
-        rp.metric = ix->metric; rp.k = (uint32_t)k; rp.eps_coef = eps; rp.nd2max_bits = ix->d_scalars;
-        rp.out_ids = d_out_ids + (size_t)q0 * k; rp.out_dists = d_out_dists + (size_t)q0 * k;
-        rp.out_counts = d_out_counts + q0; rp.out_stride = (uint32_t)k; rp.cert = d_cert + q0; rp.status = d_status;
-        rp.thr = ix->cur->w_thr.p + q0;
-        rp.qerr = ix->cur->w_qerr.p + q0; rp.c_acc = c_acc_bf16(ix); rp.lb_scores = ix->d_margin ? 1u : 0u;
-        rp.kp_first = round_up((uint32_t)k + 38u, 16u); rp.kp_step = 32;
-        rp.thr_next = d_thr_next ? d_thr_next + q0 : nullptr;
-        // diagnostics build: the first re-rank round overridden, the depth each query ended at printed
-        if (ix->kn.kp_first) rp.kp_first = ix->kn.kp_first;
-        const bool dump_depth = ix->kn.rr_depth;
-        if (dump_depth) {
-            if ((rc = W->w_depth.ensure(SUPER * 17))) return rc;      // depth[q], then 8 x 64-bit phase stamps per query
-            rp.depth = W->w_depth.p;
-        }
-        vdb::launch_rerank(rp, nb, s);
-        if (dump_depth) {
-            std::vector<uint32_t> dep((size_t)SUPER * 17);
-            HIP_TRY(hipMemcpyAsync(dep.data(), W->w_depth.p, dep.size() * 4, hipMemcpyDeviceToHost, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            // phase stamps (s_memrealtime, 100 MHz): 0 start, 1 query row in LDS, 2 round 1 staged+folded, 3 sorted, 4 depth decided, 5 last round folded, 6 end
-            const uint64_t* st64 = reinterpret_cast<const uint64_t*>(dep.data() + SUPER);
-            uint64_t t0 = ~0ull;
-            for (uint32_t q = 0; q < nb; ++q) t0 = std::min(t0, st64[(size_t)q * 8]);
-            double med[7];
-            for (int ph = 0; ph < 7; ++ph) {
-                std::vector<double> v(nb);
-                for (uint32_t q = 0; q < nb; ++q) v[q] = (double)(st64[(size_t)q * 8 + ph] - t0) * 0.01;
-                std::sort(v.begin(), v.end());
-                med[ph] = v[nb / 2];
-                fprintf(stderr, "[vdb] re-rank phase %d at us: min %.2f median %.2f p90 %.2f max %.2f\n", ph, v[0], v[nb / 2], v[(size_t)nb * 9 / 10], v[nb - 1]);
+            vdb::RerankParams rp{};
+            rp.rows = ix->d_rows; rp.ld = ld; rp.dim = ix->dim; rp.n_rows = n;
+            rp.qp = ix->cur->w_qp.p + (size_t)qb0 * ld; rp.qnorm = ix->cur->w_qnorm.p + qb0; rp.nd = ix->d_nd; rp.row_ids = ix->d_row_ids;
+            rp.rowmask = d_rowmask; rp.cand = W->w_cand.p; rp.cand_stride = kp; rp.cand_cnt = d_cand_cnt; rp.kp = kp;
+            rp.metric = ix->metric; rp.k = (uint32_t)k; rp.eps_coef = eps; rp.nd2max_bits = ix->d_scalars;
+            rp.out_ids = d_out_ids + (size_t)qb0 * k; rp.out_dists = d_out_dists + (size_t)qb0 * k;
+            rp.out_counts = d_out_counts + qb0; rp.out_stride = (uint32_t)k; rp.cert = d_cert + qb0; rp.status = d_status;
+            rp.thr = ix->cur->w_thr.p + qb0;
+            rp.qerr = ix->cur->w_qerr.p + qb0; rp.c_acc = c_acc_bf16(ix); rp.lb_scores = ix->d_margin ? 1u : 0u;
+            rp.kp_first = round_up((uint32_t)k + 38u, 16u); rp.kp_step = 32;
+            rp.thr_next = d_thr_next ? d_thr_next + qb0 : nullptr;
+            // diagnostics build: the first re-rank round overridden, the depth each query ended at printed
+            if (ix->kn.kp_first) rp.kp_first = ix->kn.kp_first;
+            const bool dump_depth = ix->kn.rr_depth;
+            if (dump_depth) {
+                if ((rc = W->w_depth.ensure(SUPER * 17))) return rc;      // depth[q], then 8 x 64-bit phase stamps per query
+                rp.depth = W->w_depth.p;
             }
-            (void)med;
-            std::sort(dep.begin(), dep.begin() + nb);
-            fprintf(stderr, "[vdb] re-rank depth of %u queries: min %u  p25 %u  median %u  p75 %u  p95 %u  max %u  (first round %u)\n", nb,
-                    dep[0], dep[nb / 4], dep[nb / 2], dep[(size_t)nb * 3 / 4], dep[(size_t)nb * 95 / 100], dep[nb - 1], rp.kp_first);
+            vdb::launch_rerank(rp, nb, s);
+            if (dump_depth) {
+                std::vector<uint32_t> dep((size_t)SUPER * 17);
+                HIP_TRY(hipMemcpyAsync(dep.data(), W->w_depth.p, dep.size() * 4, hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                // phase stamps (s_memrealtime, 100 MHz): 0 start, 1 query row in LDS, 2 round 1 staged+folded, 3 sorted, 4 depth decided, 5 last round folded, 6 end
+                const uint64_t* st64 = reinterpret_cast<const uint64_t*>(dep.data() + SUPER);
+                uint64_t t0 = ~0ull;
+                for (uint32_t q = 0; q < nb; ++q) t0 = std::min(t0, st64[(size_t)q * 8]);
+                for (int ph = 0; ph < 7; ++ph) {
+                    std::vector<double> v(nb);
+                    for (uint32_t q = 0; q < nb; ++q) v[q] = (double)(st64[(size_t)q * 8 + ph] - t0) * 0.01;
+                    std::sort(v.begin(), v.end());
+                    fprintf(stderr, "[vdb] re-rank phase %d at us: min %.2f median %.2f p90 %.2f max %.2f\n", ph, v[0], v[nb / 2], v[(size_t)nb * 9 / 10], v[nb - 1]);
+                }
+                std::sort(dep.begin(), dep.begin() + nb);
+                fprintf(stderr, "[vdb] re-rank depth of %u queries: min %u  p25 %u  median %u  p75 %u  p95 %u  max %u  (first round %u)\n", nb,
+                        dep[0], dep[nb / 4], dep[nb / 2], dep[(size_t)nb * 3 / 4], dep[(size_t)nb * 95 / 100], dep[nb - 1], rp.kp_first);
+            }
         }
+        q0 += n_blocks * SUPER;
     }
     if (alt) {                                                   // the caller's stream continues behind BOTH chains
         HIP_TRY(hipEventRecord(ix->ev_pass[1], Sv[1]));

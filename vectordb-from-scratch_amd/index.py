@@ -295,6 +295,12 @@ class GpuFlatIndex(Index):
         if rc:
             _raise(rc)
 
+    def set_wide(self, on=True):
+        """Batches above 256 queries: 512 queries per fetch of the rows (default) or 256.  Results are identical."""
+        rc = self._L.vdb_flat_set_wide(self._h, 1 if on else 0)
+        if rc:
+            _raise(rc)
+
     TIERS_NO_RETHRESHOLD, TIERS_FORCE_F32, TIERS_FORCE_EXACT = 1, 2, 4
 
     def set_shadow(self, on=True):
