@@ -126,6 +126,7 @@ struct SelectParams {
     // keys[(q*n_sub + s)*capl + j], j < sub_counts[q*n_sub + s]
     const uint32_t* sub_counts; uint32_t n_sub; uint32_t capl;
     uint32_t wg_major;                                 // 1: sub-pool i = wg*4 + r of query q has its count at (wg*256 + q)*4 + r and its keys at that * capl (bf16 tier)
+    size_t blk_keys, blk_cnts;                         // wg_major, more than 256 queries in one launch: query q lives in block q >> 8, whose pools start blk_keys keys / blk_cnts counts after the previous block's
     uint32_t kk;                                       // how many smallest keys to keep (<= 2048)
     uint64_t* out_keys; uint32_t out_stride;           // sorted ascending, padded with EMPTY_KEY
     uint32_t* out_cnt;

@@ -495,11 +495,15 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
         // thread's loads are in flight together.
         const uint32_t* sc = p.sub_counts + (size_t)q * p.n_sub;
         const uint64_t* base = p.keys + (size_t)q * p.n_sub * p.capl;
+        // (bf16 tier, several 256-query blocks in one launch: the block's pools, the query's place inside its block)
+        const uint32_t ql = p.wg_major ? (q & 255u) : q;
+        const uint32_t* wg_cnts = p.sub_counts + (size_t)(q >> 8) * p.blk_cnts;
+        const uint64_t* wg_keys = p.keys + (size_t)(q >> 8) * p.blk_keys;
         bool over = false;
         for (uint32_t i0 = 0; i0 < p.n_sub; i0 += SEL_THREADS) {
             const uint32_t i = i0 + tid;
             // (bf16 tier: counts workgroup-major like the keys -- four consecutive threads read one workgroup's 16 bytes)
-            uint32_t c = i < p.n_sub ? (p.wg_major ? p.sub_counts[((size_t)(i >> 2) * 256u + q) * 4u + (i & 3u)] : sc[i]) : 0u;
+            uint32_t c = i < p.n_sub ? (p.wg_major ? wg_cnts[((size_t)(i >> 2) * 256u + ql) * 4u + (i & 3u)] : sc[i]) : 0u;
             if (c > p.capl) { c = p.capl; over = true; }
             uint32_t incl = c;
             for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(incl, o); if ((int)lane >= o) incl += t; }
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
             wbase = __shfl(wbase, 63);
             uint32_t pos = wbase + incl - c;
             // (bf16 tier: keys workgroup-major, sub-pool i = wg*4 + r of query q at ((wg*256 + q)*4 + r)*capl)
-            const uint64_t* src = p.wg_major ? p.keys + (((size_t)(i >> 2) * 256u + q) * 4u + (i & 3u)) * p.capl : base + (size_t)i * p.capl;
+            const uint64_t* src = p.wg_major ? wg_keys + (((size_t)(i >> 2) * 256u + ql) * 4u + (i & 3u)) * p.capl : base + (size_t)i * p.capl;
             for (uint32_t j0 = 0; j0 < c; j0 += 4) {
                 uint64_t k[4];
 #pragma unroll

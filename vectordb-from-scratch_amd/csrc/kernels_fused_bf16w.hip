@@ -106,8 +106,11 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
     const uint32_t ntiles = SAMPLE ? 1u : ntiles_rt;
     // queries of this lane: one column in each of the wave's two 32-query MFMA tiles
     const uint32_t q_a = wq * 64 + c, q_b = q_a + 32;
-    uint64_t* pool_a = nullptr; uint64_t* pool_b = nullptr;
-    size_t sub_a = 0, sub_b = 0;
+    // (query b = query a + 32: its count and its pool sit 128 sub-pools further -- derived where they are needed, in the rare path
+    // and at the end, instead of being held in two more registers across the stage loop: the kernel is at the 256-VGPR limit, and
+    // a pointer spilled to scratch cost a vmcnt(0) -- a drain of the DMA ring -- at every append)
+    uint64_t* pool_a = nullptr;
+    size_t sub_a = 0;
     float thr_a = 0.f, thr_b = 0.f;
     if (!SAMPLE) {
         // pools: the ordinary workgroup-major pools of the query's 256-query BLOCK (see kernels_fused_bf16p.hip), sub-pools 0 / 1
@@ -115,22 +118,20 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
         const uint32_t blk = q_a >> 8;                                  // q_a and q_b lie in the same block (64-query wave ranges)
         const size_t cnt_base = (size_t)blk * p.cnt_block_stride;
         sub_a = cnt_base + ((size_t)blockIdx.x * QB + (q_a & 255u)) * 4 + h;
-        sub_b = cnt_base + ((size_t)blockIdx.x * QB + (q_b & 255u)) * 4 + h;
         uint64_t* const pool_blk = p.pool + (size_t)blk * p.pool_block_stride;
         pool_a = pool_blk + (((size_t)blockIdx.x * QB + (q_a & 255u)) * 4 + h) * p.capl;
-        pool_b = pool_blk + (((size_t)blockIdx.x * QB + (q_b & 255u)) * 4 + h) * p.capl;
         thr_a = p.thr[q_a];
         thr_b = p.thr[q_b];
         // consume the two loads here: a first use inside the stage loop would get a compiler-inserted vmcnt(0)
         // there, i.e. a wait for every DMA in flight, once per tile
-        if (p.ablate & 16u) thr_a = thr_b = -__builtin_inff();       // diagnostics: nothing passes the filter (cost of the append path)
+        if (p.ablate & 16u) thr_a = thr_b = -3.0e38f;              // diagnostics: nothing passes the filter (cost of the append path; finite, so that the MARGIN instance's loosened threshold is not inf - inf)
         asm volatile("" : "+v"(thr_a), "+v"(thr_b));
     }
     uint32_t pcnt_a = 0, pcnt_b = 0;
     // can a score of this launch be NaN at all?  (wave-uniform; decides how the epilogue tests four scores at once)
     const bool no_nan = !SAMPLE && fused_no_nan(p.scalars, p.qmax_bits, !MARGIN);
     if (ntiles == 0) {
-        p.pool_cnt[sub_a] = 0; p.pool_cnt[sub_b] = 0; p.pool_cnt[sub_a + 2] = 0; p.pool_cnt[sub_b + 2] = 0;
+        p.pool_cnt[sub_a] = 0; p.pool_cnt[sub_a + 128] = 0; p.pool_cnt[sub_a + 2] = 0; p.pool_cnt[sub_a + 130] = 0;
         return;
     }
     const uint32_t total = ntiles * KS;
@@ -399,87 +400,96 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
                 thp_a = fmaf(ga, mm, thr_a); thp_a += (fabsf(thr_a) + ga * mm) * 6.0e-7f;
                 thp_b = fmaf(gb, mm, thr_b); thp_b += (fabsf(thr_b) + gb * mm) * 6.0e-7f;
             }
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const uint32_t vbits = (uint32_t)(val[i >> 1] >> (32 * (i & 1) + 4 * h));
-                const uint32_t rowb = wr * 128 + i * 32 + 4 * h;       // tile-row of element (j = 0, e = 0)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(al + i * 32 + 8 * j);
-                    const float4 b4 = *reinterpret_cast<const float4*>(be + i * 32 + 8 * j);
-                    // scores of 4 rows x 2 queries
-                    // (two rows per v_pk_fma_f32: the same IEEE fma per element, half the instructions)
-                    const f32x2 al01 = {a4.x, a4.y}, al23 = {a4.z, a4.w}, be01 = {b4.x, b4.y}, be23 = {b4.z, b4.w};
-                    const f32x2 pa01 = {acc[i][0][4 * j + 0], acc[i][0][4 * j + 1]}, pa23 = {acc[i][0][4 * j + 2], acc[i][0][4 * j + 3]};
-                    const f32x2 pb01 = {acc[i][1][4 * j + 0], acc[i][1][4 * j + 1]}, pb23 = {acc[i][1][4 * j + 2], acc[i][1][4 * j + 3]};
-                    const f32x2 ra01 = __builtin_elementwise_fma(pa01, al01, be01), ra23 = __builtin_elementwise_fma(pa23, al23, be23);
-                    const f32x2 rb01 = __builtin_elementwise_fma(pb01, al01, be01), rb23 = __builtin_elementwise_fma(pb23, al23, be23);
-                    const float sa0 = ra01.x, sa1 = ra01.y, sa2 = ra23.x, sa3 = ra23.y;
-                    const float sb0 = rb01.x, sb1 = rb01.y, sb2 = rb23.x, sb3 = rb23.y;
-                    const uint32_t rt0 = rowb + 8 * j;                  // tile-row of element 0
-                    if (SAMPLE) {
-                        // smallest score of the lane's eligible rows (v_min_f32 skips a NaN score: such a row is no witness
-                        // for a threshold, and it reaches the re-rank through the filter pass, which keeps NaN scores)
-                        const float inf_ = __uint_as_float(0x7f800000u);
-#define VDB_MIN(E, SA, SB)                                                                             \
-    {                                                                                                  \
-        const bool ok_ = (vbits >> (8 * j + (E))) & 1u;                                                \
-        best_a = fminf(best_a, ok_ ? (SA) : inf_);                                                     \
-        best_b = fminf(best_b, ok_ ? (SB) : inf_);                                                     \
-    }
-                        VDB_MIN(0, sa0, sb0) VDB_MIN(1, sa1, sb1) VDB_MIN(2, sa2, sb2) VDB_MIN(3, sa3, sb3)
-#undef VDB_MIN
-                    } else {
-                        // Hits are rare (about 0.1 % of the elements).  ONE compare per query for the four rows: the smallest of the four
-                        // scores against the threshold, its lane mask straight into the not-taken branch; the append code is out of
-                        // line.  v_min_f32 drops a NaN operand and a NaN score must pass (flat_index.rs:62) -- so this form is used
-                        // as it stands only when no score of the launch can be NaN (fused_no_nan: every norm within
-                        // [2^-40, 2^40]); otherwise a NaN-propagating sum of the four is tested as well (inf - inf gives a
-                        // false alarm, which the exact per-row test of the rare path sorts out).
-                        const f32x2 na_ = __builtin_elementwise_min(ra01, ra23), nb_ = __builtin_elementwise_min(rb01, rb23);
-                        unsigned long long ma = __builtin_amdgcn_ballot_w64(!(fminf(na_.x, na_.y) > thp_a));
-                        unsigned long long mb = __builtin_amdgcn_ballot_w64(!(fminf(nb_.x, nb_.y) > thp_b));
-                        if (__builtin_expect(!no_nan, 0)) {                  // a real (wave-uniform) branch: the empty asm keeps hipcc from
-                            asm volatile("" ::: "memory");                   // computing the sums always and selecting with v_cndmask
-                            const f32x2 ua_ = ra01 + ra23, ub_ = rb01 + rb23;
-                            const float ta_ = ua_.x + ua_.y, tb_ = ub_.x + ub_.y;
-                            ma |= __builtin_amdgcn_ballot_w64(ta_ != ta_);
-                            mb |= __builtin_amdgcn_ballot_w64(tb_ != tb_);
-                        }
-                        if (kDiag && (p.ablate & 4096u)) {                  // diag 4096: round 1's four compares per query (A/B)
-                            ma = __builtin_amdgcn_ballot_w64(!(sa0 > thp_a) || !(sa1 > thp_a) || !(sa2 > thp_a) || !(sa3 > thp_a));
-                            mb = __builtin_amdgcn_ballot_w64(!(sb0 > thp_b) || !(sb1 > thp_b) || !(sb2 > thp_b) || !(sb3 > thp_b));
-                        }
-                        // The append path is what the epilogue costs (with thresholds that let nothing pass the kernel is as
-                        // fast as without an epilogue), so it is kept short: one 4-bit hit mask per lane and query, then a
-                        // loop over its set bits -- typically one lane, one iteration -- instead of four masked regions.
-#define VDB_APPEND(S0, S1, S2, S3, THP, THR, NG, POOL, PCNT)                                           \
+            // Per row block i (32 rows x 2 queries per lane = 4 groups of 4 rows): the COMMON path is branch-free -- scores of the four
+            // groups, the minimum of each group against the (loosened) threshold, the four lane masks OR-ed on the scalar unit --
+            // and ends in ONE not-taken branch per query.  (Until round 3 every group of 4 rows had its own three branches, with the
+            // LDS reads of its constants issued right in front of their use: 48 branch points and 16 exposed LDS round trips per
+            // tile made the epilogue ~5 us per tile, a fifth of the wide kernel's time, although appends are rare; without branches
+            // between the groups the compiler hoists the LDS reads and interleaves the groups.)  Hits are rare (about 0.1 % of the
+            // elements), so the RARE path recomputes the block's scores for its query from the accumulators -- nothing of the
+            // common path has to stay live for it -- and appends what passes the exact test.
+            // v_min_f32 drops a NaN operand and a NaN score must pass (flat_index.rs:62): the minimum test stands alone only when
+            // no score of the launch can be NaN (fused_no_nan: every norm within [2^-40, 2^40]); otherwise a NaN-propagating sum of
+            // each group is tested as well (inf - inf gives a false alarm, which the exact per-row test of the rare path sorts out).
+#define VDB_SCORES(I_, J_, Q_, S01, S23)                                                               \
+    const float4 a4_ = *reinterpret_cast<const float4*>(al + (I_) * 32 + 8 * (J_));                    \
+    const float4 b4_ = *reinterpret_cast<const float4*>(be + (I_) * 32 + 8 * (J_));                    \
+    const f32x2 al01_ = {a4_.x, a4_.y}, al23_ = {a4_.z, a4_.w}, be01_ = {b4_.x, b4_.y}, be23_ = {b4_.z, b4_.w}; \
+    const f32x2 p01_ = {acc[I_][Q_][4 * (J_) + 0], acc[I_][Q_][4 * (J_) + 1]}, p23_ = {acc[I_][Q_][4 * (J_) + 2], acc[I_][Q_][4 * (J_) + 3]}; \
+    const f32x2 S01 = __builtin_elementwise_fma(p01_, al01_, be01_), S23 = __builtin_elementwise_fma(p23_, al23_, be23_);
+            // the append: one 4-bit hit mask per lane and group, then a loop over its set bits -- typically one lane, one iteration
+#define VDB_APPEND(I_, J_, S0, S1, S2, S3, THP, THR, NG, POOL, PCNT)                                   \
     {                                                                                                  \
         uint32_t hm_ = (!((S0) > (THP)) ? 1u : 0u) | (!((S1) > (THP)) ? 2u : 0u) | (!((S2) > (THP)) ? 4u : 0u) | (!((S3) > (THP)) ? 8u : 0u); \
-        hm_ &= (vbits >> (8 * j)) & 0xfu;                                                              \
+        hm_ &= (vbits >> (8 * (J_))) & 0xfu;                                                           \
         while (hm_) {                                                                                  \
             const uint32_t e_ = (uint32_t)__builtin_ctz(hm_);                                          \
             hm_ &= hm_ - 1u;                                                                           \
             float sc_ = e_ == 0 ? (S0) : e_ == 1 ? (S1) : e_ == 2 ? (S2) : (S3);                       \
             if (MARGIN) {                                              /* the exact test, on the lower-bound score */ \
-                sc_ = fmaf((NG), mg[i * 32 + 8 * j + 4 * h + e_], sc_);                                \
+                sc_ = fmaf((NG), mg[(I_) * 32 + 8 * (J_) + 4 * h + e_], sc_);                          \
                 if (sc_ > (THR)) continue;                                                             \
             }                                                                                          \
-            if (!(kDiag && (p.ablate & 32u)) && PCNT < p.capl) POOL[PCNT] = make_raw_key(sc_, tr0 + rt0 + e_); /* diag 32: count only */ \
+            if (!(kDiag && (p.ablate & 32u)) && PCNT < p.capl) POOL[PCNT] = make_raw_key(sc_, tr0 + rowb + 8 * (J_) + e_); /* diag 32: count only */ \
             ++PCNT;                                                                                    \
         }                                                                                              \
     }
-                        if (kDiag && (p.ablate & 64u)) {            // diag 64: the branch is taken, the append is not executed
-                            if (__builtin_expect(ma != 0ull, 0)) { asm volatile("s_nop 1" ::: "memory"); ++pcnt_a; }
-                            if (__builtin_expect(mb != 0ull, 0)) { asm volatile("s_nop 1" ::: "memory"); ++pcnt_b; }
-                        } else {
-                        if (__builtin_expect(ma != 0ull, 0)) VDB_APPEND(sa0, sa1, sa2, sa3, thp_a, thr_a, ng_a, pool_a, pcnt_a)
-                        if (__builtin_expect(mb != 0ull, 0)) VDB_APPEND(sb0, sb1, sb2, sb3, thp_b, thr_b, ng_b, pool_b, pcnt_b)
-                        }
-#undef VDB_APPEND
+#define VDB_RARE(I_, Q_, THP, THR, NG, POOL, PCNT)                                                     \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                 \
+        VDB_SCORES(I_, j_, Q_, r01_, r23_)                                                             \
+        VDB_APPEND(I_, j_, r01_.x, r01_.y, r23_.x, r23_.y, THP, THR, NG, POOL, PCNT)                   \
+    }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const uint32_t vbits = (uint32_t)(val[i >> 1] >> (32 * (i & 1) + 4 * h));
+                const uint32_t rowb = wr * 128 + i * 32 + 4 * h;       // tile-row of element (j = 0, e = 0)
+                unsigned long long ha = 0ull, hb = 0ull;               // lanes with a possible hit in this row block, per query
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // scores of 4 rows x 2 queries (two rows per v_pk_fma_f32: the same IEEE fma per element, half the instructions)
+                    const float4 a4 = *reinterpret_cast<const float4*>(al + i * 32 + 8 * j);
+                    const float4 b4 = *reinterpret_cast<const float4*>(be + i * 32 + 8 * j);
+                    const f32x2 al01 = {a4.x, a4.y}, al23 = {a4.z, a4.w}, be01 = {b4.x, b4.y}, be23 = {b4.z, b4.w};
+                    const f32x2 pa01 = {acc[i][0][4 * j + 0], acc[i][0][4 * j + 1]}, pa23 = {acc[i][0][4 * j + 2], acc[i][0][4 * j + 3]};
+                    const f32x2 pb01 = {acc[i][1][4 * j + 0], acc[i][1][4 * j + 1]}, pb23 = {acc[i][1][4 * j + 2], acc[i][1][4 * j + 3]};
+                    const f32x2 ra01 = __builtin_elementwise_fma(pa01, al01, be01), ra23 = __builtin_elementwise_fma(pa23, al23, be23);
+                    const f32x2 rb01 = __builtin_elementwise_fma(pb01, al01, be01), rb23 = __builtin_elementwise_fma(pb23, al23, be23);
+                    if (kDiag && (p.ablate & 4096u)) {                  // diag 4096: round 1's four compares per query (A/B)
+                        ha |= __builtin_amdgcn_ballot_w64(!(ra01.x > thp_a) || !(ra01.y > thp_a) || !(ra23.x > thp_a) || !(ra23.y > thp_a));
+                        hb |= __builtin_amdgcn_ballot_w64(!(rb01.x > thp_b) || !(rb01.y > thp_b) || !(rb23.x > thp_b) || !(rb23.y > thp_b));
+                    } else {
+                        const f32x2 na_ = __builtin_elementwise_min(ra01, ra23), nb_ = __builtin_elementwise_min(rb01, rb23);
+                        ha |= __builtin_amdgcn_ballot_w64(!(fminf(na_.x, na_.y) > thp_a));
+                        hb |= __builtin_amdgcn_ballot_w64(!(fminf(nb_.x, nb_.y) > thp_b));
+                    }
+                    // two groups in flight at a time: with all four the register allocator spills (the kernel sits at 256 VGPRs,
+                    // and a scratch access in here costs a vmcnt(0), i.e. a drain of the DMA ring, per tile)
+                    if (j & 1) __builtin_amdgcn_sched_barrier(0);
+                }
+                if (__builtin_expect(!no_nan, 0)) {                     // a real (wave-uniform) branch: the empty asm keeps hipcc from
+                    asm volatile("" ::: "memory");                      // computing the sums always and selecting with v_cndmask
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        { VDB_SCORES(i, j, 0, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; ha |= __builtin_amdgcn_ballot_w64(t_ != t_); }
+                        { VDB_SCORES(i, j, 1, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; hb |= __builtin_amdgcn_ballot_w64(t_ != t_); }
+                    }
+                }
+                if (kDiag && (p.ablate & 64u)) {                        // diag 64: the branch is taken, the append is not executed
+                    if (__builtin_expect(ha != 0ull, 0)) { asm volatile("s_nop 1" ::: "memory"); ++pcnt_a; }
+                    if (__builtin_expect(hb != 0ull, 0)) { asm volatile("s_nop 1" ::: "memory"); ++pcnt_b; }
+                } else {
+                    if (__builtin_expect(ha != 0ull, 0)) VDB_RARE(i, 0, thp_a, thr_a, ng_a, pool_a, pcnt_a)
+                    if (__builtin_expect(hb != 0ull, 0)) {
+                        uint64_t* pool_b = pool_a;
+                        asm volatile("" : "+v"(pool_b));               // (keeps hipcc from hoisting the sum out of the loop into a register)
+                        pool_b += (size_t)128 * p.capl;
+                        VDB_RARE(i, 1, thp_b, thr_b, ng_b, pool_b, pcnt_b)
                     }
                 }
             }
+#undef VDB_RARE
+#undef VDB_APPEND
+#undef VDB_SCORES
             if (SAMPLE) {
                 // one group minimum per (tile, row half, lane half) and query
                 const uint32_t g = (((tile_first + tile * tile_step) * 2 + wr) * 2 + h);
@@ -514,9 +524,9 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
     if (st < total) { run_stage(st, B0{}, std::false_type{}); ++st; }
     if (st < total) { run_stage(st, B1{}, std::false_type{}); ++st; }
     p.pool_cnt[sub_a] = pcnt_a;
-    p.pool_cnt[sub_b] = pcnt_b;
+    p.pool_cnt[sub_a + 128] = pcnt_b;                                   // query b = query a + 32: 4 counts per query
     p.pool_cnt[sub_a + 2] = 0;                                          // sub-pools 2 / 3 of the block's layout: unused by this shape
-    p.pool_cnt[sub_b + 2] = 0;
+    p.pool_cnt[sub_a + 130] = 0;
 #undef VDB_DMA
 #undef VDB_DMA_NT
 #undef VDB_DMA_OFF

@@ -239,12 +239,46 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
     }
     ix->cur->stats[4] = S;
     const float eps = eps_coef(ix);
+    // thresholds: sample pass + threshold select per 256-query block.  A batch of several passes computes ALL of them first, on the
+    // caller's stream: left to their own pass, the second stream's small kernels queue up behind the first pass's filter kernel
+    // (which owns every CU for a millisecond) and the second filter pass starts late.
+    auto thresholds_of = [&](Workspace* W, hipStream_t st, uint32_t qb0) {
+        const uint32_t nb = std::min(SUPER, nq - qb0);
+        vdb::FusedBf16Params fp{};
+        fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n;
+        fp.alpha = ix->d_alpha; fp.beta = ix->d_beta; fp.rowmask = d_rowmask ? d_rowmask : ix->d_live;
+        fp.margin = ix->d_margin;
+        fp.pool = W->w_pool.p; fp.pool_cnt = W->w_subcnt.p; fp.capl = capl; fp.n_wg = n_wg;
+        fp.scalars = ix->d_scalars; fp.qmax_bits = d_status + 2;
+        fp.ablate = ix->kn.bf16_ablate;
+        fp.n_sample = S; fp.sample_shift = pl.shift;
+        fp.sample_block = ix->kn.sample_block ? (n / (S / 256u)) : 0u; fp.minkeys = W->w_dense.p; fp.minkey_stride = M;
+        fp.qb = ix->cur->w_qb.p + (size_t)qb0 * ld; fp.qg = ix->d_margin ? ix->cur->w_qg.p + qb0 : nullptr; fp.thr = ix->cur->w_thr.p + qb0;
+        if (sample_copy) {
+            vdb::FusedBf16Params sp16 = fp;
+            sp16.rows16 = ix->d_sample16;
+            vdb::launch_sample_s16(sp16, st);
+        } else vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, st);
+        vdb::SelectParams sp{};
+        sp.keys = W->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = KT;
+        sp.out_stride = KT; sp.out_keys = W->w_samp.p; sp.out_cnt = W->w_cnt.p; sp.out_thr = ix->cur->w_thr.p + qb0; sp.ovf = nullptr;
+        if (ix->d_margin) { sp.shift_g = ix->cur->w_qg.p + qb0; sp.shift_m_bits = ix->d_scalars + 4; }   // plain-score sample -> lower-bound units
+        vdb::launch_thr_select(sp, nb, st);
+    };
+    // (measured at config 3's shape: four 256-query passes 3.26 -> 3.09 ms with the thresholds first; the two 512-query passes
+    // are better off with their own -- 2.75 against 2.84 ms: the second pass's thresholds then run beside the first pass's tail)
+    const uint32_t n_passes = use_wide ? (nq + 2 * SUPER - 1) / (2 * SUPER) : (nq + SUPER - 1) / SUPER;
+    const bool thr_first = alt != nullptr && n_passes > 2;
+    if (thr_first) {
+        for (uint32_t qb0 = 0; qb0 < nq; qb0 += SUPER) thresholds_of(ix->cur, s, qb0);
+        HIP_TRY(hipEventRecord(ix->ev_pass[0], s));               // (re-recorded: the other stream starts behind the thresholds)
+        HIP_TRY(hipStreamWaitEvent(Sv[1], ix->ev_pass[0], 0));
+    }
     for (uint32_t q0 = 0, pass = 0; q0 < nq; ++pass) {
         const bool wide = use_wide && nq - q0 > SUPER;            // two 256-query blocks share this pass's fetch of the rows
         const uint32_t n_blocks = wide ? 2u : 1u;
         Workspace* const W = Wv[pass & 1];                        // pass-local buffers
         const hipStream_t s = Sv[pass & 1];                       // (shadows the caller's stream inside the loop)
-        uint32_t* d_cnt_a = W->w_cnt.p;
         uint32_t* d_cand_cnt = W->w_cnt.p + 2 * SUPER;
         vdb::FusedBf16Params fp{};
         fp.rows = ix->d_rows; fp.ld = ld; fp.n_rows = n;
@@ -255,22 +289,9 @@ int pass_bf16(Index* ix, hipStream_t s, uint32_t nq, size_t k, const Bf16Plan& p
         fp.ablate = ix->kn.bf16_ablate;
         fp.n_sample = S; fp.sample_shift = pl.shift;
         fp.sample_block = ix->kn.sample_block ? (n / (S / 256u)) : 0u; fp.minkeys = W->w_dense.p; fp.minkey_stride = M;
-        // ---- thresholds of the pass's blocks: sample pass + threshold select per 256 queries
-        for (uint32_t b = 0; b < n_blocks; ++b) {
-            const uint32_t qb0 = q0 + b * SUPER, nb = std::min(SUPER, nq - qb0);
-            fp.qb = ix->cur->w_qb.p + (size_t)qb0 * ld; fp.qg = ix->d_margin ? ix->cur->w_qg.p + qb0 : nullptr; fp.thr = ix->cur->w_thr.p + qb0;
-            if (sample_copy) {
-                vdb::FusedBf16Params sp16 = fp;
-                sp16.rows16 = ix->d_sample16;
-                vdb::launch_sample_s16(sp16, s);
-            } else vdb::launch_sample_bf16(fp, (uint32_t)ix->n_cu, s);
-
-            vdb::SelectParams sp{};
-            sp.keys = W->w_dense.p; sp.stride = M; sp.counts = nullptr; sp.n_fixed = M; sp.cap = M; sp.kk = KT;
-            sp.out_stride = KT; sp.out_keys = W->w_samp.p; sp.out_cnt = d_cnt_a; sp.out_thr = ix->cur->w_thr.p + qb0; sp.ovf = nullptr;
-            if (ix->d_margin) { sp.shift_g = ix->cur->w_qg.p + qb0; sp.shift_m_bits = ix->d_scalars + 4; }   // plain-score sample -> lower-bound units
-            vdb::launch_thr_select(sp, nb, s);
-        }
+        // ---- thresholds of the pass's blocks (unless they were all computed up front)
+        if (!thr_first)
+            for (uint32_t b = 0; b < n_blocks; ++b) thresholds_of(W, s, q0 + b * SUPER);
         // ---- ONE pass over the rows for all of them
         fp.qb = ix->cur->w_qb.p + (size_t)q0 * ld; fp.qg = ix->d_margin ? ix->cur->w_qg.p + q0 : nullptr; fp.thr = ix->cur->w_thr.p + q0;
         if (ix->profile) HIP_TRY(hipEventRecord(ix->ev0, s));
