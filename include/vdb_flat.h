@@ -293,6 +293,7 @@ int vdb_flat_set_sample_cache(vdb_flat_index *h, int on);
 #define VDB_TIERS_NO_RETHRESHOLD 1u /* skip the re-threshold pass: uncertified queries go straight to the f32 MFMA tier */
 #define VDB_TIERS_FORCE_F32 2u      /* hand EVERY query the screening tier answered to the f32 MFMA tier as well */
 #define VDB_TIERS_FORCE_EXACT 4u    /* hand every query to the exact scan */
+#define VDB_TIERS_NO_DIRECT 8u      /* small indexes (<= 16384 rows), batches of <= 8 queries: the tiered pipeline instead of the direct exact scan */
 int vdb_flat_set_tiers(vdb_flat_index *h, unsigned flags);
 
 /*

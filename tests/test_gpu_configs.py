@@ -28,8 +28,9 @@ def test_c1_flat_10k_x_128_euclid_single_query_at_its_own_shape(vdb):
     """BASELINE configs[0] = benches/search_bench.rs:18-33: 10,000 x 128 uniform[0,1) rows, Euclidean, k = 10, ONE query
     [0.5; 128] -- the literal FlatIndex::search drop-in (src/flat_index.rs:52-65), one vdb_flat_search call.  10k rows take the
     dense-scores path (indexes up to 16384 rows: every row scored by the f32-input MFMA kernel, no filter pass), the only size
-    of BASELINE that does.  Whole result against the oracle, bit for bit; k = 10000 (the full sort the reference performs)
-    through the exact-scan path as well."""
+    of BASELINE that does -- and, for batches of up to 8 queries, the DIRECT path: one exact-scan kernel + one select/emit kernel
+    through mapped host memory (the latency of a call is the measure here, bench.py --config c1).  Whole result against the
+    oracle, bit for bit, through both; k = 10000 (the full sort the reference performs) through the exact-scan path as well."""
     import ctypes
     n, d, k = 10_000, 128, 10
     rows = np.random.default_rng(0).random((n, d), dtype=np.float32)
@@ -47,7 +48,16 @@ def test_c1_flat_10k_x_128_euclid_single_query_at_its_own_shape(vdb):
     oi, od = oracle.flat_search(0, rows, q, k)
     assert out_c.value == k and np.array_equal(out_i, oi) and np.array_equal(out_d.view(np.uint32), od.view(np.uint32))
     st = ix.last_stats()
+    assert st["exact_queries"] == 1 and st["mfma_queries"] == 0 and st["rows_scanned"] == 0, st    # the direct path: an exact scan, two kernels
+    # the same call through the tiered pipeline (dense f32-MFMA scores of every row, certified re-rank): same bits
+    ix.set_tiers(ix.TIERS_NO_DIRECT)
+    out2_i, out2_d, out2_c = np.zeros(k, dtype=np.uint64), np.zeros(k, dtype=np.float32), ctypes.c_size_t()
+    rc = L.vdb_flat_search(ix._h, q.ctypes.data_as(fp), d, k, out2_i.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), out2_d.ctypes.data_as(fp),
+                           ctypes.byref(out2_c))
+    assert rc == 0 and out2_c.value == k and np.array_equal(out2_i, oi) and np.array_equal(out2_d.view(np.uint32), od.view(np.uint32))
+    st = ix.last_stats()
     assert st["bf16_screen"] == 0 and st["sample_rows"] == n and st["rows_scanned"] == 0 and st["exact_queries"] == 0, st    # dense scores of every row, certified
+    ix.set_tiers(0)
     res = ix.search(vdb.Vector(q), k)                               # the trait method of the Python mirror: same call underneath
     assert [r[0] for r in res] == list(oi) and np.array_equal(np.array([r[1] for r in res], dtype=np.float32).view(np.uint32), od.view(np.uint32))
     # self-query: distance exactly 0 first (distance.rs:89-93)

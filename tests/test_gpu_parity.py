@@ -527,3 +527,67 @@ def test_sample_cache_with_two_searches_of_different_sample_size_in_flight(vdb):
     gi, gd, gc = ix.search_batch_arrays(qh, 10)
     oi, od = oracle.flat_search(1, rows, qh[3], 10)
     assert np.array_equal(gi[3], oi) and np.array_equal(gd[3].view(np.uint32), od.view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_direct_path_of_small_indexes_equals_the_tiered_pipeline_and_the_oracle(vdb, metric):
+    """Indexes of at most 16384 rows, batches of at most 8 queries: two kernels (exact scan of every row in the reference's
+    operation order, select + emit) through mapped host memory.  Same ids, order, counts and distance bits as the tiered
+    pipeline (VDB_TIERS_NO_DIRECT) and as the oracle -- with tombstones, sparse non-monotone ids, an id mask, per-query k, k > n,
+    exact ties, and the reference's error semantics."""
+    rng = np.random.default_rng(40 + metric)
+    n, d = 9000, 70
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[100] = rows[7000]                                             # an exact tie, decided by id
+    ids = rng.permutation(np.arange(1, 40 * n, 37, dtype=np.uint64))[:n]      # sparse, not monotone
+    ix = vdb.GpuFlatIndex(vdb.DistanceMetric(metric), keep_host_copy=False)
+    ix.add_bulk(rows, ids=ids)
+    dead = np.zeros(n, dtype=bool); dead[::13] = True
+    for i in ids[dead]:
+        ix.remove(int(i))
+    live = (~dead).astype(np.uint8)
+    q = rng.standard_normal((8, d)).astype(np.float32)
+    q[3] = rows[100]
+    ks = np.array([1, 10, 64, 3, 2048, 7, 100, 5000], dtype=np.uintp)   # 5000 > 2048: that batch takes the tiered pipeline by itself
+    for qsel, kk in ((slice(0, 7), ks[:7]), (slice(0, 1), 10), (slice(0, 8), 10), (slice(0, 8), ks)):
+        qq = q[qsel]
+        a = ix.search_batch_arrays(qq, kk)
+        st = ix.last_stats()
+        kmax = int(np.max(kk))
+        assert st["exact_queries"] == (len(qq) if kmax <= 2048 else st["exact_queries"]), st
+        ix.set_tiers(ix.TIERS_NO_DIRECT)
+        b = ix.search_batch_arrays(qq, kk)
+        ix.set_tiers(0)
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+        for bq in range(len(qq)):
+            kb = int(kk if np.isscalar(kk) else kk[bq])
+            oi, od = oracle.flat_search(metric, rows, qq[bq], kb, ids=ids, live=live)
+            assert a[2][bq] == len(oi) and np.array_equal(a[0][bq, :len(oi)], oi) and np.array_equal(a[1][bq, :len(od)].view(np.uint32), od.view(np.uint32))
+    # id mask (pre-filter) through the direct path: host-pointer entry point falls back to its device staging, the path is the same
+    mlive = (rng.random(int(ids.max()) + 1) < 0.2)
+    mask = np.packbits(mlive.astype(np.uint8), bitorder="little")
+    mask = np.concatenate([mask, np.zeros((-len(mask)) % 8, dtype=np.uint8)]).view(np.uint64)
+    m = ix.search_batch_arrays(q[:4], 10, id_mask=mask, mask_bits=len(mlive))
+    assert ix.last_stats()["exact_queries"] == 4
+    lv = live & mlive[ids.astype(np.int64)].astype(np.uint8)
+    for bq in range(4):
+        oi, od = oracle.flat_search(metric, rows, q[bq], 10, ids=ids, live=lv)
+        assert m[2][bq] == len(oi) and np.array_equal(m[0][bq, :len(oi)], oi) and np.array_equal(m[1][bq, :len(od)].view(np.uint32), od.view(np.uint32))
+    # errors: dimension mismatch, zero-norm query and a zero-norm row under Cosine, NaN
+    with pytest.raises(vdb.DimensionMismatch):
+        ix.search_batch_arrays(np.ones((1, d + 3), dtype=np.float32), 5)
+    if metric == 1:
+        with pytest.raises(vdb.InvalidVector):
+            ix.search_batch_arrays(np.zeros((2, d), dtype=np.float32), 5)
+        ix.add(10**9, vdb.Vector(np.zeros(d, dtype=np.float32)))
+        with pytest.raises(vdb.InvalidVector):
+            ix.search_batch_arrays(q[:2], 5)
+        ix.remove(10**9)
+    qn = q[:2].copy(); qn[1, 5] = np.nan
+    with pytest.raises(vdb.NanDistance):
+        ix.search_batch_arrays(qn, 5)
+    again = ix.search_batch_arrays(q[:7], ks[:7])                        # the handle stays usable, the status word was cleaned
+    first = ix.search_batch_arrays(q[:7], ks[:7])
+    for x, y in zip(again, first):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))

@@ -138,6 +138,12 @@ struct SelectParams {
     uint32_t flag_truncation;                          // 1: more valid keys than kk also sets ovf[q] (the caller needs ALL of them)
     const uint64_t* lo_excl;                           // may be null: only keys > lo_excl[q] take part (chunked large k)
     uint64_t* out_last;                                // may be null: largest selected key per query (unchanged if none)
+    // EMIT (may be null; keys = ordered(exact distance) << 32 | id rank, as the exact scans write them): the selected keys are
+    // also written as final results -- emit_ids / emit_dists [q * emit_stride + i], emit_counts[q] -- and the search's status
+    // word is copied to emit_status[q].  The outputs may live in mapped host memory (the small-index direct path).
+    uint64_t* emit_ids; float* emit_dists; uint32_t* emit_counts; uint32_t emit_stride;
+    const uint32_t* emit_rank2row; const uint64_t* emit_row_ids;
+    const uint32_t* emit_status_in; uint32_t* emit_status;
 };
 void launch_select(const SelectParams& p, uint32_t nq, hipStream_t s);
 // The screening tier's THRESHOLD select: only the score of the kk-th smallest of n_fixed <= 4096 keys per query is wanted
@@ -266,6 +272,25 @@ void launch_rerank(const RerankParams& p, uint32_t nq, hipStream_t s);
 // exhaustive variant: EVERY candidate of the list (up to cand_stride, any order) is re-ranked, the best k are kept;
 // cert[q] = 1 unless the list was truncated upstream (the caller's overflow flag) or a NaN score was seen
 void launch_rerank_all(const RerankParams& p, uint32_t nq, hipStream_t s);
+
+// ---------------------------------------------------------------- direct exact scan of a SMALL index for a few queries
+// Index::search as it stands (flat_index.rs:52-65) for indexes of at most 16384 rows and batches of at most 8 queries -- the shape
+// of BASELINE configs[0] (10k x 128, ONE query): every row's exact distance in the reference's operation order, straight from
+// the raw queries (which may live in mapped host memory): no query preparation pass, no MFMA scores, no certificate.
+struct SmallScanParams {
+    const float* rows; uint32_t ld; uint32_t dim; uint32_t n_rows;
+    const float* q_in; uint32_t nq;                    // [nq][dim] as handed over
+    const float* nd; const uint32_t* rowmask; const uint32_t* idrank; int metric;
+    uint64_t* keys; uint32_t key_stride;               // key = ordered(dist) << 32 | id rank, EMPTY if ineligible
+    // keep == 0: keys[q * key_stride + row], every row's key.  keep = k' < 256: every workgroup of 256 rows keeps only its k'
+    // smallest keys (any global top-k with k <= k' is among them): keys[q * key_stride + workgroup * k' + i], EMPTY padded --
+    // the select then sees n/256 * k' keys instead of n (10k rows, k = 10: 400 keys, ranked by counting in ~3 us instead of
+    // seven radix passes over 10k keys in 57 us)
+    uint32_t keep;
+    uint32_t* status;                                  // ST_NAN / ST_ZERO_QUERY
+};
+void launch_small_scan(const SmallScanParams& p, hipStream_t s);
+uint32_t small_scan_groups(uint32_t n_rows);           // workgroups along the rows
 
 // ---------------------------------------------------------------- exact scan (fallback, any k)
 struct ExactScanParams {

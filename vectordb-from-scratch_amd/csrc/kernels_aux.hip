@@ -470,6 +470,20 @@ constexpr uint32_t SEL_LDS_KEYS = 16384;  // keys cached in LDS when n fits (128
 constexpr uint32_t SEL_MAX_KK = 2048;
 constexpr uint32_t SEL_THREADS = 1024;   // 16 waves per query: the passes are latency-bound
 
+// EMIT mode: selected key i of query q as a final (id, distance) result
+__device__ __forceinline__ void select_emit(const SelectParams& p, uint32_t q, uint32_t i, uint64_t key, bool valid) {
+    const size_t o = (size_t)q * p.emit_stride + i;
+    if (valid) {
+        const uint32_t rk = (uint32_t)key;
+        const uint32_t row = p.emit_rank2row ? p.emit_rank2row[rk] : rk;
+        p.emit_ids[o] = p.emit_row_ids[row];
+        p.emit_dists[o] = ordered_to_f32((uint32_t)(key >> 32));
+    } else {
+        p.emit_ids[o] = ~0ull;
+        p.emit_dists[o] = __uint_as_float(0x7fc00000u);
+    }
+}
+
 __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
     extern __shared__ __attribute__((aligned(16))) uint64_t sdyn[];
     uint64_t* sKeys = sdyn;                       // [SEL_LDS_KEYS]
@@ -551,8 +565,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
     const uint32_t kk = nvalid < p.kk ? nvalid : p.kk;
     if (p.flag_truncation && nvalid > p.kk && p.ovf && tid == 0) { p.ovf[q] = 1u; if (p.summary) atomicOr(p.summary, 2u); }
     uint64_t* out = p.out_keys + (size_t)q * p.out_stride;
+    if (p.emit_ids && tid == 0) { p.emit_counts[q] = kk; if (p.emit_status) p.emit_status[q] = *p.emit_status_in; }
     if (kk == 0) {
         for (uint32_t i = tid; i < p.kk; i += SEL_THREADS) out[i] = EMPTY_KEY;
+        if (p.emit_ids) for (uint32_t i = tid; i < p.emit_stride; i += SEL_THREADS) select_emit(p, q, i, 0, false);
         if (tid == 0) { p.out_cnt[q] = 0; if (p.out_thr) p.out_thr[q] = __uint_as_float(0x7f800000u); }
         return;
     }
@@ -573,6 +589,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
         }
         if (mine != EMPTY_KEY && rank < kk) out[rank] = mine;
         for (uint32_t i = kk + tid; i < p.kk; i += SEL_THREADS) out[i] = EMPTY_KEY;
+        if (p.emit_ids) {
+            if (mine != EMPTY_KEY && rank < kk) select_emit(p, q, rank, mine, true);
+            for (uint32_t i = kk + tid; i < p.emit_stride; i += SEL_THREADS) select_emit(p, q, i, 0, false);
+        }
         if (mine != EMPTY_KEY && rank == kk - 1) {                  // the kk-th smallest key: exactly one thread
             p.out_cnt[q] = kk;
             if (p.out_last) p.out_last[q] = mine;
@@ -693,6 +713,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(SelectParams p) {
         }
     }
     for (uint32_t i = tid; i < p.kk; i += SEL_THREADS) out[i] = i < kk ? sOut[i] : EMPTY_KEY;
+    if (p.emit_ids) for (uint32_t i = tid; i < p.emit_stride; i += SEL_THREADS) select_emit(p, q, i, i < kk ? sOut[i] : 0, i < kk);
     if (tid == 0) {
         p.out_cnt[q] = kk;
         if (p.out_last) p.out_last[q] = sOut[kk - 1];
@@ -1366,6 +1387,61 @@ __global__ __launch_bounds__(256) void exact_scan_kernel(ExactScanParams p) {
 void launch_exact_scan(const ExactScanParams& p, hipStream_t s) {
     if (!p.n_rows) return;
     hipLaunchKernelGGL(exact_scan_kernel, dim3((p.n_rows + 255) / 256), dim3(256), 0, s, p);
+}
+
+// The direct path of small indexes (SmallScanParams): blockIdx.y = query.  The workgroup stages the RAW query row in LDS (it may
+// come from mapped host memory: one read over PCIe per workgroup), every thread computes the exact-order query norm it needs
+// under Cosine from there (vector.rs:35-37: sqrt of the left fold of x*x; the same value in every thread), then one row per
+// thread in the reference's operation order -- exact_distance, the function the re-rank and the exact scans use.
+__global__ __launch_bounds__(256) void small_scan_kernel(SmallScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sQ[];         // [round_up(dim, 4)]
+    const uint32_t q = blockIdx.y;
+    const float* src = p.q_in + (size_t)q * p.dim;
+    for (uint32_t i = threadIdx.x; i < p.dim; i += blockDim.x) sQ[i] = src[i];
+    __syncthreads();
+    float qn = 0.0f;
+    if (p.metric == COSINE) {
+        qn = __builtin_sqrtf(fold_sq(sQ, p.dim));
+        if (qn == 0.0f && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(p.status, ST_ZERO_QUERY);   // distance.rs:51-55
+    }
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool ok = row < p.n_rows && (p.rowmask ? ((p.rowmask[row >> 5] >> (row & 31)) & 1u) : true);
+    uint64_t key = EMPTY_KEY;
+    if (ok) {
+        const float dist = exact_distance(p.metric, sQ, p.rows + (size_t)row * p.ld, p.dim, qn, p.nd[row]);
+        if (dist != dist) atomicOr(p.status, ST_NAN);
+        const uint32_t rk = p.idrank ? p.idrank[row] : row;
+        key = ((uint64_t)f32_to_ordered(dist) << 32) | rk;
+    }
+    if (p.keep == 0) {
+        if (row < p.n_rows) p.keys[(size_t)q * p.key_stride + row] = key;
+        return;
+    }
+    // the workgroup's `keep` smallest keys, by counting (valid keys are distinct: the id rank is their low word)
+    __shared__ __attribute__((aligned(16))) uint64_t sK[256];
+    __shared__ uint32_t sValid;
+    if (threadIdx.x == 0) sValid = 0;
+    sK[threadIdx.x] = key;
+    __syncthreads();
+    const unsigned long long vb = __ballot(key != EMPTY_KEY);
+    if ((threadIdx.x & 63) == 0 && vb) atomicAdd(&sValid, (uint32_t)__popcll(vb));
+    uint32_t rank = 0;
+    if (key != EMPTY_KEY) {
+        for (uint32_t j = 0; j < 256; j += 2) {
+            const ulonglong2 k2 = *reinterpret_cast<const ulonglong2*>(sK + j);
+            rank += (k2.x < key) + (k2.y < key);
+        }
+    }
+    __syncthreads();
+    uint64_t* out = p.keys + (size_t)q * p.key_stride + (size_t)blockIdx.x * p.keep;
+    if (key != EMPTY_KEY && rank < p.keep) out[rank] = key;
+    const uint32_t nv = sValid < p.keep ? sValid : p.keep;
+    if (threadIdx.x >= nv && threadIdx.x < p.keep) out[threadIdx.x] = EMPTY_KEY;
+}
+uint32_t small_scan_groups(uint32_t n_rows) { return (n_rows + 255) / 256; }
+void launch_small_scan(const SmallScanParams& p, hipStream_t s) {
+    if (!p.n_rows || !p.nq) return;
+    hipLaunchKernelGGL(small_scan_kernel, dim3((p.n_rows + 255) / 256, p.nq), dim3(256), (size_t)((p.dim + 3) & ~3u) * sizeof(float), s, p);
 }
 
 // One pass over the rows for up to 8 queries: one thread per row, the row is read once (16 floats at a

@@ -131,6 +131,8 @@ void vdb_flat_destroy(vdb_flat_index* ix) {
         Workspace& W = ix->wsv[w];
         W.for_each_buffer([](auto& buf) { buf.release(); });
         if (W.h_flags) (void)hipHostFree(W.h_flags);
+        if (W.h_dstat) (void)hipHostFree(W.h_dstat);
+        if (W.h_io) (void)hipHostFree(W.h_io);
         if (w == 1 && W.stream) { (void)hipStreamSynchronize(W.stream); (void)hipStreamDestroy(W.stream); }
     }
     delete[] ix->wsv;
@@ -491,6 +493,29 @@ int vdb_flat_search_batch(vdb_flat_index* ix, const float* queries, size_t nq, s
     size_t len = ix->n_live + ix->misfits.size();
     size_t kdev = std::min(kmax, std::max<size_t>(len, 1));
     hipStream_t s = ix->stream;
+    // Small index, a few queries (BASELINE configs[0]: Index::search itself, one query): queries and results go through MAPPED
+    // host memory -- the two kernels of the direct path read and write it in place, nothing is copied by the runtime
+    if (direct_eligible(ix, ix->n_rows(), nq, kdev) && ix->misfits.empty() && dim == ix->dim && !id_mask) {
+        const size_t qb = nq * dim * sizeof(float), ib = nq * kdev * sizeof(uint64_t), db = nq * kdev * sizeof(float), cb = nq * sizeof(uint32_t);
+        const size_t o_i = (qb + 15) & ~(size_t)15, o_d = o_i + ib, o_c = o_d + ((db + 15) & ~(size_t)15);
+        if ((rc = ensure_host_io(ix, o_c + cb))) return rc;
+        Workspace* W = ix->cur;
+        memcpy(W->h_io, queries, qb);
+        rc = search_device(ix, reinterpret_cast<const float*>(W->d_h_io), nq, dim, kdev, nullptr, 0, reinterpret_cast<uint64_t*>(W->d_h_io + o_i),
+                           reinterpret_cast<float*>(W->d_h_io + o_d), reinterpret_cast<uint32_t*>(W->d_h_io + o_c), nullptr);
+        if (rc) return rc;
+        W = &ix->wsv[0];                                           // (search_device leaves ix->cur at workspace 0, the one it used)
+        const uint64_t* h_ids = reinterpret_cast<const uint64_t*>(W->h_io + o_i);
+        const float* h_ds = reinterpret_cast<const float*>(W->h_io + o_d);
+        const uint32_t* h_cnt = reinterpret_cast<const uint32_t*>(W->h_io + o_c);
+        for (size_t b = 0; b < nq; ++b) {
+            const size_t kb = ks ? ks[b] : k;
+            const size_t c = std::min<size_t>(h_cnt[b], kb);       // per-query k: a prefix of the batch-wide result
+            out_counts[b] = c;
+            for (size_t i = 0; i < c; ++i) { out_ids[b * kstride + i] = h_ids[b * kdev + i]; out_dists[b * kstride + i] = h_ds[b * kdev + i]; }
+        }
+        return VDB_OK;
+    }
     if ((rc = ix->cur->w_qin.ensure(nq * std::max<size_t>(dim, 1)))) return rc;
     if ((rc = ix->cur->w_outi.ensure(nq * std::max<size_t>(kdev, 1)))) return rc;
     if ((rc = ix->cur->w_outd.ensure(nq * std::max<size_t>(kdev, 1)))) return rc;
@@ -887,7 +912,7 @@ int vdb_flat_set_shadow(vdb_flat_index* ix, int on) {
 
 int vdb_flat_set_tiers(vdb_flat_index* ix, unsigned flags) {
     return guarded([&]() -> int {
-    if (!ix || (flags & ~7u)) return fail(VDB_ERR_INVALID_ARGUMENT, "flags must be a combination of VDB_TIERS_*");
+    if (!ix || (flags & ~15u)) return fail(VDB_ERR_INVALID_ARGUMENT, "flags must be a combination of VDB_TIERS_*");
     if (ix->multi) return multi_for_each(ix, [flags](vdb_flat_index* c) { return vdb_flat_set_tiers(c, flags); });
     std::lock_guard<std::mutex> g(ix->mu);
     ix->tiers = flags;

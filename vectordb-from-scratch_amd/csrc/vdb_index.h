@@ -78,6 +78,7 @@ inline uint32_t pow2_ceil(uint64_t x) {
 constexpr uint32_t SMALL_N = 16384;     // at or below: dense scores of every row, no fused pass
 constexpr uint32_t SUPER = 256;         // queries per pipeline pass
 constexpr uint32_t MAX_SELECT = 2048;   // select kernel capacity (kk)
+constexpr uint32_t DIRECT_MAX_Q = 8;    // the direct exact path of small indexes takes batches up to this many queries
 
 }  // namespace vdbi
 
@@ -93,6 +94,11 @@ struct Workspace {
     vdbi::DevBuf<uint16_t> w2_qb;
     vdbi::DevBuf<uint32_t> w2_outc, w2_flags, w2_qidx;
     uint32_t* h_flags = nullptr; size_t h_flags_n = 0;
+    // the direct path of small indexes (search_direct): a device status word known to be zero between searches, and MAPPED host
+    // memory -- the kernels write results and status straight into it (h_io: the host-pointer entry point's queries and outputs)
+    vdbi::DevBuf<uint32_t> w_dstat; bool dstat_ready = false;
+    uint32_t* h_dstat = nullptr; uint32_t* d_h_dstat = nullptr;       // [16] host view / device view
+    char* h_io = nullptr; char* d_h_io = nullptr; size_t h_io_bytes = 0;
     bool status_dirty = true; uint32_t* status_buf = nullptr;   // device status block known to be zero?
     // a search between its two halves (search_part1 enqueues the first tier, search_part2 reads its flags and runs
     // the fallback tiers): vdb_flat_search_batch_device_begin / _finish keep the handle locked in between
@@ -113,7 +119,7 @@ struct Workspace {
         f(w_dense); f(w_samp); f(w_pool); f(w_cand); f(w_exact); f(w_exsel); f(w_mask_ids); f(w_outi);
         f(w_cnt); f(w_rowmask); f(w_flags); f(w_outc); f(w_subcnt); f(w_depth); f(w_qb);
         f(w2_qp); f(w2_qnorm); f(w2_thr); f(w2_outd); f(w2_qerr); f(w2_qg); f(w2_outi); f(w2_cand); f(w2_qb);
-        f(w2_outc); f(w2_flags); f(w2_qidx);
+        f(w2_outc); f(w2_flags); f(w2_qidx); f(w_dstat);
     }
 };
 
@@ -232,6 +238,8 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
                  size_t mask_bits, uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts,
                  hipStream_t user_stream, bool allow_alt = false);
 int search_part2(Index* ix, int* changed);
+bool direct_eligible(const Index* ix, size_t n_rows, size_t nq, size_t k);
+int ensure_host_io(Index* ix, size_t bytes);
 void publish_stats(Index* ix);
 bool in_flight(const Index* ix);
 int refuse_in_flight();

@@ -464,6 +464,76 @@ int pass_rethreshold(Index* ix, hipStream_t s, const std::vector<uint32_t>& todo
     return VDB_OK;
 }
 
+// ------------------------------------------------------------------ the direct path of small indexes
+// Index::search as it stands (flat_index.rs:52-65) -- every row's exact distance, the k smallest by (distance, id) -- for an
+// index of at most 16384 rows and a batch of at most DIRECT_MAX_Q queries: BASELINE configs[0] (benches/search_bench.rs:18-33:
+// 10k x 128, ONE query).  At that size the tiered pipeline is five launches of latency (query preparation, dense MFMA scores,
+// select, re-rank, flag copy: ~90 us per call); here it is TWO kernels and one stream synchronisation -- small_scan_kernel reads
+// the raw queries (from wherever they are: the host-pointer entry point hands over MAPPED host memory, so no copy is enqueued at
+// all) and writes one exact key per row, select_kernel in EMIT mode writes ids, distances, counts and the status word straight
+// into the caller's buffers (mapped host memory again for the host-pointer entry point).  Exact by construction: no certificate.
+bool direct_eligible(const Index* ix, size_t n_rows, size_t nq, size_t k) {
+    return !(ix->tiers & VDB_TIERS_NO_DIRECT) && n_rows > 0 && n_rows <= SMALL_N && nq > 0 && nq <= DIRECT_MAX_Q && k > 0 && k <= MAX_SELECT;
+}
+
+int ensure_host_io(Index* ix, size_t bytes) {
+    Workspace* W = ix->cur;
+    if (bytes <= W->h_io_bytes) return VDB_OK;
+    if (W->h_io) (void)hipHostFree(W->h_io);
+    W->h_io = W->d_h_io = nullptr; W->h_io_bytes = 0;
+    const size_t cap = std::max<size_t>(bytes + bytes / 2, 1u << 16);
+    HIP_TRY(hipHostMalloc((void**)&W->h_io, cap, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&W->d_h_io, W->h_io, 0));
+    W->h_io_bytes = cap;
+    return VDB_OK;
+}
+
+static int search_direct(Index* ix, hipStream_t s, const float* d_q, uint32_t nq, size_t k, const uint32_t* d_rowmask,
+                         uint64_t* d_out_ids, float* d_out_dists, uint32_t* d_out_counts) {
+    int rc;
+    Workspace* W = ix->cur;
+    const uint32_t n = ix->n_uploaded;
+    if ((rc = ensure_ranks(ix))) return rc;
+    // every workgroup of the scan keeps its k smallest keys only (k < 256): the select ranks n/256 * k keys instead of n
+    const uint32_t keep = k < 256 ? (uint32_t)k : 0u;
+    const uint32_t n_keys = keep ? vdb::small_scan_groups(n) * keep : n;
+    if ((rc = W->w_exact.ensure((size_t)nq * std::max(n_keys, n)))) return rc;
+    if ((rc = W->w_exsel.ensure((size_t)nq * MAX_SELECT + 8))) return rc;
+    if ((rc = W->w_cnt.ensure(4 * SUPER + 16))) return rc;
+    if (!W->dstat_ready) {
+        if ((rc = W->w_dstat.ensure(4))) return rc;
+        if (!W->h_dstat) {
+            HIP_TRY(hipHostMalloc((void**)&W->h_dstat, 16 * sizeof(uint32_t), hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void**)&W->d_h_dstat, W->h_dstat, 0));
+        }
+        HIP_TRY(hipMemsetAsync(W->w_dstat.p, 0, 16, s));
+        W->dstat_ready = true;
+    }
+    vdb::SmallScanParams sp{ix->d_rows, ix->ld, ix->dim, n, d_q, nq, ix->d_nd, d_rowmask, ix->ids_monotone ? nullptr : ix->d_idrank.p,
+                            ix->metric, W->w_exact.p, n_keys, keep, W->w_dstat.p};
+    vdb::launch_small_scan(sp, s);
+    vdb::SelectParams mp{};
+    mp.keys = W->w_exact.p; mp.stride = n_keys; mp.counts = nullptr; mp.n_fixed = n_keys; mp.cap = n_keys;
+    mp.kk = (uint32_t)k; mp.out_keys = W->w_exsel.p; mp.out_stride = MAX_SELECT; mp.out_cnt = W->w_cnt.p;
+    mp.emit_ids = d_out_ids; mp.emit_dists = d_out_dists; mp.emit_counts = d_out_counts; mp.emit_stride = (uint32_t)k;
+    mp.emit_rank2row = ix->ids_monotone ? nullptr : ix->d_rank2row.p; mp.emit_row_ids = ix->d_row_ids;
+    mp.emit_status_in = W->w_dstat.p; mp.emit_status = W->d_h_dstat;
+    vdb::launch_select(mp, nq, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    uint32_t status = 0;
+    for (uint32_t q = 0; q < nq; ++q) status |= W->h_dstat[q];
+    ix->cur->stats[1] = nq;                                         // answered by an exact scan
+    if (status) {                                                  // (rare: leave the device word clean for the next search)
+        HIP_TRY(hipMemsetAsync(W->w_dstat.p, 0, 16, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (status & vdb::ST_ZERO_QUERY)
+        return fail(VDB_ERR_INVALID_VECTOR, "Invalid vector: Cannot compute cosine distance with zero vector");
+    if (status & vdb::ST_NAN) return fail(VDB_ERR_NAN, "NaN distance (the reference panics here, flat_index.rs:62)");
+    return VDB_OK;
+}
+
 // Part 1: checks, workspace, and the FIRST tier enqueued on the stream -- no host synchronisation unless the search is
 // one of the cases answered completely here (empty store, k = 0, k too large for the MFMA tiers).
 int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, const uint64_t* d_idmask,
@@ -509,6 +579,19 @@ int search_part1(Index* ix, const float* d_q, size_t nq, size_t dim, size_t k, c
     const uint32_t nq32 = (uint32_t)nq;
     const uint32_t bp_all = round_up(nq32, SUPER);
     const uint32_t kp = pick_kp(k);
+
+    // ---- small index, a few queries: the direct exact path (two kernels, answered completely here)
+    if (direct_eligible(ix, n, nq, k)) {
+        const uint32_t* d_rowmask = (ix->n_live == n) ? nullptr : ix->d_live;
+        if (d_idmask) {
+            if ((rc = ix->cur->w_rowmask.ensure((n + 31) / 32))) return rc;
+            vdb::launch_build_rowmask(ix->d_row_ids, d_rowmask, d_idmask, mask_bits, n, ix->cur->w_rowmask.p, s);
+            d_rowmask = ix->cur->w_rowmask.p;
+        }
+        rc = search_direct(ix, s, d_q, nq32, k, d_rowmask, d_out_ids, d_out_dists, d_out_counts);
+        ix->cur->stats[10] = ix->cur->stats[11] = ix->cur->stats[12] = since();
+        return rc;
+    }
 
     // ---- workspace
     if ((rc = ix->cur->w_qp.ensure((size_t)bp_all * ld))) return rc;

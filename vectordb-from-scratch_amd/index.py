@@ -301,7 +301,7 @@ class GpuFlatIndex(Index):
         if rc:
             _raise(rc)
 
-    TIERS_NO_RETHRESHOLD, TIERS_FORCE_F32, TIERS_FORCE_EXACT = 1, 2, 4
+    TIERS_NO_RETHRESHOLD, TIERS_FORCE_F32, TIERS_FORCE_EXACT, TIERS_NO_DIRECT = 1, 2, 4, 8
 
     def set_shadow(self, on=True):
         """Opt-in bf16 shadow of the rows for the screening pass (include/vdb_flat.h: +50 % device memory, half the HBM bytes
