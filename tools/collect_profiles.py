@@ -41,4 +41,32 @@ tj["workload"] = "bench.py default (1Mx768 f32, batch 256, k=10, 1 GPU)"
 json.dump(tj, open(tpath, "w"), indent=1)
 bench = open(os.path.join(root, "gpurun_out/bench_final.json")).read().strip().splitlines()[-1]
 open(os.path.join(root, f"profiles/{tag}_bench_line.json"), "w").write(bench + "\n")
+# ---- config 3's shape (tools/round_profile.sh): kernel stats, bench line, FETCH / WRITE of the wide filter kernel per launch
+try:
+    shutil.copy(newest("gpurun_out/profS3/*/*kernel_stats.csv"), os.path.join(root, f"profiles/{tag}_c3_kernel_stats.csv"))
+    for cfg in ("c3", "c1", "c4"):
+        f = os.path.join(root, f"gpurun_out/bench_{cfg}.json")
+        if os.path.exists(f) and open(f).read().strip():
+            open(os.path.join(root, f"profiles/{tag}_{cfg}_bench_line.json"), "w").write(open(f).read().strip().splitlines()[-1] + "\n")
+    c3 = {}
+    for d in ("pmcF3", "pmcW3"):
+        cc = newest(f"gpurun_out/{d}/*/*counter_collection.csv")
+        agg = collections.defaultdict(lambda: collections.defaultdict(float)); kname = None
+        for r in csv.DictReader(open(cc)):
+            if "fused_bf16" in r["Kernel_Name"]:
+                agg[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"]); kname = r["Kernel_Name"]
+        last = sorted(agg, key=int)[-1]
+        c3[d] = dict(agg[last]); c3["kernel"] = kname
+    f3 = c3["pmcF3"]["FETCH_SIZE"] * 1024; w3 = c3["pmcW3"]["WRITE_SIZE"] * 1024
+    rows_bytes = 1250000 * 768 * 4
+    c3["_notes"] = {"workload": "bench.py --config c3: one 1.25M x 768 shard, dot, batch 1024 (two launches of 512 queries), k = 100",
+                    "fetch_raw_bytes_per_launch": f3, "write_bytes_per_launch": w3, "hbm_bytes_per_launch": 2 * f3 + w3,
+                    "rows_bytes": rows_bytes, "launches_per_batch": 2,
+                    "hbm_bytes_per_batch_filter_passes": 2 * (2 * f3 + w3), "algorithmic_bytes_per_batch": rows_bytes + 1024 * 768 * 4,
+                    "rows_read_per_batch": 2 * (2 * f3 + w3) / rows_bytes,
+                    "correction": "FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM section)"}
+    json.dump(c3, open(os.path.join(root, f"profiles/{tag}_pmc_c3.json"), "w"), indent=1)
+    print("c3:", json.dumps(c3["_notes"]))
+except Exception as e:
+    print("c3 profile not collected:", e)
 print(json.dumps({k: v for k, v in out.items() if k != "_notes"}, indent=1)[:1800]); print(out["_notes"]["hbm_bytes_per_launch"])
