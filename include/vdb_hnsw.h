@@ -77,6 +77,17 @@ int vdb_hnsw_entry_point(const vdb_hnsw_index *h, uint64_t *id, size_t *max_leve
  * device walk overflowed its LDS structures and that the host traversal re-ran. */
 int vdb_hnsw_stats(const vdb_hnsw_index *h, uint64_t out[6]);
 
+/* How bulk inserts (vdb_hnsw_add_bulk, 32 vectors or more) get their distances.  1 (default): FRONTIER ONLY -- a device walk per
+ * insert evaluates what search_layer asks for (graph.rs:155, :182) on the graph as of the start of its chunk of 256 inserts, the
+ * host replays the inserts in order with the reference's algorithm and asks the GPU again only where the real walk left the
+ * speculative one.  0: the row-scan build (every stored row against every new vector, N^2 / 2 distances).  Same graph either way. */
+int vdb_hnsw_set_build(vdb_hnsw_index *h, int frontier_only);
+/* Counters of the builds since creation: [0] inserts of the frontier-only build, [1] distances its device walks evaluated,
+ * [2] distances between vectors of one chunk, [3] distances evaluated after a miss (the real walk left the speculative one),
+ * [4] such round trips, [5] walks whose record overflowed, [6] distances the host's inserts consumed (what the reference's
+ * algorithm evaluates), [7] inserts of the row-scan build. */
+int vdb_hnsw_build_stats(const vdb_hnsw_index *h, uint64_t out[8]);
+
 #ifdef __cplusplus
 }
 #endif

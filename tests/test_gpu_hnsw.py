@@ -191,3 +191,77 @@ def test_recall_floors_of_the_reference(vdb, n, dim, nq, floor):
     rec = np.mean([len(set(ti[b]) & set(hi[b, :hc[b]])) / 10.0 for b in range(nq)])
     assert rec >= floor, rec
     assert np.all(hd[:, 1:] >= hd[:, :-1])
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_frontier_only_build_equals_the_scan_build_and_the_cpu_restatement(vdb, metric):
+    """bulk inserts used to fold every new vector against every stored row (N^2 / 2 distances).  The default
+    build now runs a device walk per insert that evaluates only what search_layer asks for (graph.rs:155, :182) on the graph as
+    of the start of its chunk of 256, and the host replays the inserts in order -- the SAME graph, node for node, as the
+    row-scan build and as the CPU restatement; the GPU evaluates a small multiple of the distances the reference's algorithm
+    consumes, not N^2 / 2."""
+    rng = np.random.default_rng(90 + metric)
+    n, d, m, efc = 6000, 64, 12, 100
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    rows[3000:3040] = rows[100:140]                                    # duplicates: exact ties inside the walks
+    g, o, ids = build_pair(vdb, metric, rows, m, efc, 50, seed=11 + metric)          # default: frontier only
+    assert_same_graph(g, o, ids)
+    bs = g.build_stats()
+    assert bs["frontier_inserts"] == n and bs["scan_inserts"] == 0, bs
+    gpu = bs["walk_distances"] + bs["in_chunk_distances"] + bs["miss_distances"]
+    assert bs["reference_distances"] > 0 and gpu <= 3 * bs["reference_distances"], bs     # within 3x of what the algorithm evaluates
+    assert gpu < n * (n - 1) // 2, bs                                                   # (the row scans' count; at 6000 nodes a walk still sees a sixth of the graph)
+    assert bs["record_overflows"] == 0, bs
+    g2 = vdb.GpuHnswIndex(vdb.DistanceMetric(metric), vdb.HnswParams.new(m, efc, 50), seed=11 + metric)
+    g2.set_build(False)                                                # the row-scan build of round 2
+    g2.build_batch((ids, rows))
+    assert g2.build_stats()["scan_inserts"] == n
+    assert g2.entry_point() == g.entry_point()
+    for i in range(0, n, 7):
+        lv = g.level(i)
+        assert g2.level(i) == lv
+        for l in range(lv + 1):
+            assert g2.neighbors(i, l) == g.neighbors(i, l), (i, l)
+    queries = rng.standard_normal((20, d)).astype(np.float32)
+    assert_same_results(g, o, queries, 10, 100)
+    # a second bulk on top of the first (the mirror grows incrementally), single adds in between, a removal (full rebuild)
+    more = rng.standard_normal((700, d)).astype(np.float32)
+    g.build_batch((np.arange(n, n + 700, dtype=np.uint64), more))
+    for i, v in enumerate(more):
+        o.insert(n + i, v)
+    g.add(n + 700, vdb.Vector(rows[5])); o.insert(n + 700, rows[5])
+    g.remove(17); o.remove(17)
+    extra = rng.standard_normal((64, d)).astype(np.float32)
+    g.build_batch((np.arange(n + 701, n + 765, dtype=np.uint64), extra))
+    for i, v in enumerate(extra):
+        o.insert(n + 701 + i, v)
+    all_ids = np.arange(n + 765, dtype=np.uint64)
+    assert_same_graph(g, o, all_ids)
+    assert_same_results(g, o, queries, 10, 100)
+
+
+def test_frontier_only_build_reports_a_zero_norm_row_like_the_reference(vdb):
+    """mod.rs:37-42: build_batch returns at the first failing insert; that node is stored without links, later vectors are not."""
+    rng = np.random.default_rng(5)
+    rows = rng.standard_normal((200, 16)).astype(np.float32)
+    rows[120] = 0.0
+    g = vdb.GpuHnswIndex(vdb.DistanceMetric.Cosine, vdb.HnswParams.new(8, 40, 20), seed=3)
+    o = oracle.HnswOracle(1, m=8, ef_construction=40, ef_search=20, seed=3)
+    with pytest.raises(vdb.InvalidVector):
+        g.build_batch((np.arange(200, dtype=np.uint64), rows))
+    failed = False
+    for i, v in enumerate(rows):
+        try:
+            o.insert(i, v)
+        except Exception:
+            failed = True
+            break
+    assert failed and g.len() == len(o) == 121
+    assert_same_graph(g, o, np.arange(120, dtype=np.uint64))
+    # the level generator is where the reference's would be: the next inserts draw the same levels
+    g.remove(120); o.remove(120)
+    nxt = rng.standard_normal((40, 16)).astype(np.float32)
+    g.build_batch((np.arange(300, 340, dtype=np.uint64), nxt))
+    for i, v in enumerate(nxt):
+        o.insert(300 + i, v)
+    assert_same_graph(g, o, np.concatenate([np.arange(120), np.arange(300, 340)]).astype(np.uint64))

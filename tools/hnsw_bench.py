@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--efc", type=int, default=200)
     ap.add_argument("--metric", type=int, default=0)
     ap.add_argument("--oracle", action="store_true")
+    ap.add_argument("--scan-build", action="store_true", help="the row-scan build of round 2 (vdb_hnsw_set_build(h, 0)) instead of the frontier-only build")
     a = ap.parse_args()
     vdb = load_package()
     vdb.build()
@@ -36,6 +37,8 @@ def main():
     queries = rng.random((a.batch, a.dim), dtype=np.float32)
     ids = np.arange(a.rows, dtype=np.uint64)
     g = vdb.GpuHnswIndex(vdb.DistanceMetric(a.metric), vdb.HnswParams.new(a.m, a.efc, 50), seed=1)
+    if a.scan_build:
+        g.set_build(False)
     t0 = time.perf_counter()
     step = 20000
     for c0 in range(0, a.rows, step):
@@ -45,6 +48,7 @@ def main():
     st = g.stats()
     print(f"build: {a.rows} x {a.dim}, m={a.m} ef_construction={a.efc}: {t_build:.1f} s "
           f"({1e3 * t_build / a.rows:.3f} ms per insert), GPU distances {st['gpu_distances']:.3e}, launches {st['gpu_launches']}", flush=True)
+    print("build stats:", g.build_stats(), flush=True)
     g.search_batch_arrays(queries, a.k, a.ef)
     t0 = time.perf_counter()
     reps = 3

@@ -396,8 +396,23 @@ struct HnswSearchParams {
     uint64_t* out_ids; float* out_dists; uint32_t* out_counts;           // [nq][k]
     uint32_t* fail;                                                      // [nq]: 1 = structures overflowed, redo on the host
     uint32_t* status;
+    // INSERT WALKS (vdb_hnsw.cpp build): the "query" is a STORED row (qrow[q], its norm nd[qrow[q]]) that the graph does not hold
+    // yet, the walk is insert()'s (graph.rs:262-297): ef = 1 above the node's level qlevel[q], ef at and below it, and every
+    // distance it evaluates is RECORDED -- rec_row / rec_d [q * rec_cap + i], rec_cnt[q] entries (may exceed rec_cap: the rest
+    // was dropped) -- for the host's authoritative replay.  All null in a search.  A zero-norm Cosine pair is recorded as
+    // rec_zero_mark and ends the walk.
+    const uint32_t* qrow; const uint32_t* qlevel;
+    uint32_t* rec_row; float* rec_d; uint32_t* rec_cnt; uint32_t rec_cap; uint32_t rec_zero_mark;
 };
 void launch_hnsw_search(const HnswSearchParams& p, uint32_t nq, hipStream_t s);
+// incremental update of the graph mirror: n0 layer-0 records [id, row, level, up_off, ids[stride0], rows[stride0]] and nU
+// upper-list records [list index, ids[strideU], rows[strideU]] (uint32 words), scattered into the mirror arrays
+struct HnswScatterParams {
+    const uint32_t* rec0; uint32_t n0; const uint32_t* recU; uint32_t nU;
+    uint32_t* row_of; uint32_t* level; uint32_t* up_off; uint32_t* nbr0; uint32_t* nbr0_row; uint32_t stride0;
+    uint32_t* nbrU; uint32_t* nbrU_row; uint32_t strideU;
+};
+void launch_hnsw_scatter(const HnswScatterParams& p, hipStream_t s);
 bool hnsw_search_supported(uint32_t dim, uint32_t ef, uint32_t k, uint32_t max_list);
 
 void launch_merge_packed(const int32_t* packed, size_t words_per_part, uint32_t nparts, uint32_t nq, uint32_t k,

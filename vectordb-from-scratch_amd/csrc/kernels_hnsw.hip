@@ -82,14 +82,17 @@ __global__ __launch_bounds__(HT) void hnsw_search_kernel(HnswSearchParams p) {
     float* sStage = reinterpret_cast<float*>(sVis + VIS_CAP);                     // [MAXP][CHS]
     __shared__ uint32_t sPendId[MAXP], sPendRow[MAXP];
     __shared__ float sPendD[MAXP];
-    __shared__ uint32_t sNP, sCont, sCur, sFail, sNVis, sZero, sNCand, sNRes;
+    __shared__ uint32_t sNP, sCont, sCur, sFail, sNVis, sZero, sNCand, sNRes, sRec;
     __shared__ uint32_t sKeyD[RES_CAP];      // final stable sort: ordered distance
     __shared__ uint32_t sKeyI[RES_CAP];      //                    position in the heap's backing array
 
     const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (uint32_t i = tid; i < ldq; i += HT) sQ[i] = p.qp[(size_t)q * p.ld + i];
-    if (tid == 0) { sFail = 0; sZero = 0; }
-    const float qn = p.qnorm[q];
+    // the query: a prepared query row, or -- insert walks -- a stored row of the index
+    const float* qsrc = p.qrow ? p.rows + (size_t)p.qrow[q] * p.ld : p.qp + (size_t)q * p.ld;
+    for (uint32_t i = tid; i < ldq; i += HT) sQ[i] = qsrc[i];
+    if (tid == 0) { sFail = 0; sZero = 0; sRec = 0; }
+    const float qn = p.qrow ? p.nd[p.qrow[q]] : p.qnorm[q];
+    const uint32_t ins_level = p.qlevel ? p.qlevel[q] : 0xffffffffu;    // 0xffffffff: a search (ef = 1 above layer 0)
     __syncthreads();
 
     // distances of sPendRow[0..np) into sPendD, in the reference's operation order
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(HT) void hnsw_search_kernel(HnswSearchParams p) {
             else if (p.metric == DOT) dist = -s;
             else {
                 const float xn = p.nd[sPendRow[tid]];
-                if (qn == 0.0f || xn == 0.0f) { sZero = 1u; dist = 0.0f; }
+                if (qn == 0.0f || xn == 0.0f) { sZero = 1u; dist = p.rec_row ? __uint_as_float(p.rec_zero_mark) : 0.0f; }
                 else {
                     float sim = __fdiv_rn(s, __fmul_rn(qn, xn));
                     if (sim < -1.0f) sim = -1.0f;
@@ -151,12 +154,23 @@ __global__ __launch_bounds__(HT) void hnsw_search_kernel(HnswSearchParams p) {
             sPendD[tid] = dist;
         }
         __syncthreads();
+        if (p.rec_row) {                                            // insert walks: every evaluated (row, distance), in order
+            const uint32_t base = sRec;
+            if (tid < np && base + tid < p.rec_cap) {
+                p.rec_row[(size_t)q * p.rec_cap + base + tid] = sPendRow[tid];
+                p.rec_d[(size_t)q * p.rec_cap + base + tid] = sPendD[tid];
+            }
+            __syncthreads();
+            if (tid == 0) sRec = base + np;
+            __syncthreads();
+        }
     };
 
     uint32_t ep = p.entry_point;
     const uint32_t ef_final = p.ef > p.k ? p.ef : p.k;
     for (int layer = (int)p.max_level; layer >= 0; --layer) {
-        const uint32_t ef = layer >= 1 ? 1u : ef_final;
+        // search: ef = 1 above layer 0 (graph.rs:400-405); insert of a node of level L: ef = 1 above L, ef_construction at and below
+        const uint32_t ef = p.qlevel ? ((uint32_t)layer > ins_level ? 1u : ef_final) : (layer >= 1 ? 1u : ef_final);
         // ---- search_layer(query, [ep], ef, layer)   (graph.rs:143-199)
         for (uint32_t i = tid; i < VIS_CAP; i += HT) sVis[i] = 0xffffffffu;
         if (tid == 0) {
@@ -284,7 +298,29 @@ __global__ __launch_bounds__(HT) void hnsw_search_kernel(HnswSearchParams p) {
     }
     if (tid == 0) {
         p.fail[q] = sFail ? 1u : 0u;
-        if (sZero) atomicOr(p.status, ST_ZERO_QUERY);
+        if (p.rec_cnt) p.rec_cnt[q] = sRec;
+        if (sZero && !p.rec_row) atomicOr(p.status, ST_ZERO_QUERY);
+    }
+}
+
+// incremental mirror update: one 64-lane workgroup per record
+__global__ __launch_bounds__(64) void hnsw_scatter_kernel(HnswScatterParams p) {
+    const uint32_t b = blockIdx.x, lane = threadIdx.x;
+    if (b < p.n0) {
+        const uint32_t* r = p.rec0 + (size_t)b * (4 + 2 * p.stride0);
+        const uint32_t id = r[0];
+        if (lane == 0) { p.row_of[id] = r[1]; p.level[id] = r[2]; p.up_off[id] = r[3]; }
+        for (uint32_t i = lane; i < p.stride0; i += 64) {
+            p.nbr0[(size_t)id * p.stride0 + i] = r[4 + i];
+            p.nbr0_row[(size_t)id * p.stride0 + i] = r[4 + p.stride0 + i];
+        }
+    } else {
+        const uint32_t* r = p.recU + (size_t)(b - p.n0) * (1 + 2 * p.strideU);
+        const uint32_t li = r[0];
+        for (uint32_t i = lane; i < p.strideU; i += 64) {
+            p.nbrU[(size_t)li * p.strideU + i] = r[1 + i];
+            p.nbrU_row[(size_t)li * p.strideU + i] = r[1 + p.strideU + i];
+        }
     }
 }
 
@@ -294,6 +330,10 @@ size_t hnsw_search_lds_bytes(uint32_t dim) {
 }
 bool hnsw_search_supported(uint32_t dim, uint32_t ef, uint32_t k, uint32_t max_list) {
     return (ef > k ? ef : k) + 1 <= RES_CAP && max_list <= MAXP && hnsw_search_lds_bytes(dim) <= 150 * 1024;   // + ~9 KB static
+}
+void launch_hnsw_scatter(const HnswScatterParams& p, hipStream_t s) {
+    if (!(p.n0 + p.nU)) return;
+    hipLaunchKernelGGL(hnsw_scatter_kernel, dim3(p.n0 + p.nU), dim3(64), 0, s, p);
 }
 void launch_hnsw_search(const HnswSearchParams& p, uint32_t nq, hipStream_t s) {
     if (!nq) return;

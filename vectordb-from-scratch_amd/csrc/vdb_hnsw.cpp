@@ -23,6 +23,7 @@
 #include <cstring>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/vdb_flat.h"
@@ -140,6 +141,18 @@ struct vdb_hnsw_index {
     float* h_scan[2] = {nullptr, nullptr}; float* d_scan[2] = {nullptr, nullptr}; size_t scan_ld = 0;
     hipStream_t scan_stream = nullptr; hipEvent_t scan_ev[2] = {nullptr, nullptr};
     bool host_only = false; size_t host_threads = 0;              // vdb_hnsw_set_traversal
+    // incremental mirror: capacity in node ids / pooled upper lists, the upper-list offset of every node, and the nodes whose
+    // lists changed since the mirror was last brought up to date (inserts touch ~33 nodes each; a bulk build syncs per chunk)
+    uint32_t cap_ids = 0, cap_upper = 0, n_upper_used = 0;
+    std::vector<uint32_t> h_up_off; std::vector<uint8_t> dirty_flag; std::vector<uint32_t> dirty;
+    bool mirror_full = true;                                      // the next sync rebuilds the whole mirror
+    uint32_t* h_stage = nullptr; uint32_t* d_stage = nullptr; size_t stage_words = 0;      // mapped staging of the scatter records
+    // speculative insert walks: per walk of a chunk its query row / level (host -> device) and its record (device -> host), mapped
+    uint32_t *h_wq = nullptr, *d_wq = nullptr;                    // [2][WALKS]: rows, levels
+    uint32_t *h_rec_row = nullptr, *d_rec_row = nullptr, *h_rec_cnt = nullptr, *d_rec_cnt = nullptr;
+    float *h_rec_d = nullptr, *d_rec_d = nullptr;
+    bool spec_build = true;                                       // vdb_hnsw_set_build: 0 = the row-scan build of round 2 (A/B, tests)
+    uint64_t bstats[8] = {0};                                     // vdb_hnsw_build_stats
     const Node* node(uint64_t id) const { return id < nodes.size() && nodes[id].present ? &nodes[id] : nullptr; }
 };
 
@@ -242,9 +255,15 @@ double next_unit(Graph* g) {
     return (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
 
-// graph.rs:244-342 with every distance of the insert taken from `scan` (scan[row] = distance(new vector, device row))
-int insert_node(Graph* g, uint64_t id, uint32_t row, long level_in, const float* scan) {
-    const size_t level = level_in >= 0 ? std::min<size_t>((size_t)level_in, g->max_layers - 1) : level_from_unit(g, next_unit(g));
+void mark_dirty(Graph* g, uint64_t id) {
+    if (id >= g->dirty_flag.size()) g->dirty_flag.resize(std::max<size_t>(id + 1, g->dirty_flag.size() * 2), 0);
+    if (!g->dirty_flag[id]) { g->dirty_flag[id] = 1; g->dirty.push_back((uint32_t)id); }
+}
+
+// graph.rs:244-342.  Every distance of the insert comes from `fetch(pending ids, out distances)` -- the reference's
+// metric.distance(vector, stored) at graph.rs:155 / :182 -- and `level` is the node's level, drawn by the caller in insert
+// order (graph.rs:118-123, level_from_unit / next_unit).
+template <class Fetch> int insert_node(Graph* g, uint64_t id, uint32_t row, size_t level, Fetch&& fetch) {
     if (id >= g->nodes.size()) g->nodes.resize(id + 1);
     g->graph_version++;
     Node& nd = g->nodes[id];
@@ -253,6 +272,7 @@ int insert_node(Graph* g, uint64_t id, uint32_t row, long level_in, const float*
     nd.nbr.assign(level + 1, {});
     nd.nbr_d.assign(level + 1, {});
     g->count++;
+    mark_dirty(g, id);
     if (!g->has_ep) { g->has_ep = true; g->ep = id; g->max_level = level; return VDB_OK; }
     uint64_t ep_id = g->ep;
     const size_t cur_max = g->max_level;
@@ -262,8 +282,9 @@ int insert_node(Graph* g, uint64_t id, uint32_t row, long level_in, const float*
         ls.start(g, ep_id, ef, layer);
         while (ls.next_request()) {
             d.resize(ls.pending.size());
-            for (size_t i = 0; i < d.size(); ++i) d[i] = scan[g->nodes[ls.pending[i]].row];
-            g->stats[0] += d.size();
+            int frc = fetch(ls.pending, d);
+            if (frc) return frc;
+            g->bstats[6] += d.size();
             ls.feed(d.data());
             if (ls.zero_norm) return zero_norm_error();
         }
@@ -293,6 +314,7 @@ int insert_node(Graph* g, uint64_t id, uint32_t row, long level_in, const float*
         for (size_t i = 0; i < take; ++i) {
             Node& nb = g->nodes[nearest[i].id];
             if (!nb.present || l >= nb.nbr.size()) continue;
+            mark_dirty(g, nearest[i].id);
             nb.nbr[l].push_back(id);
             nb.nbr_d[l].push_back(nearest[i].d);                  // d(nb, new) == d(new, nb), bit for bit
             if (nb.nbr[l].size() <= m) continue;
@@ -310,6 +332,11 @@ int insert_node(Graph* g, uint64_t id, uint32_t row, long level_in, const float*
     if (level > g->max_level) { g->ep = id; g->max_level = level; }
     return VDB_OK;
 }
+
+int sync_mirror(vdb_hnsw_index* g, hipStream_t s, size_t reserve_ids, size_t reserve_upper);
+bool walks_supported(const Graph* g);
+int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n, const std::vector<uint32_t>& rowv,
+                      const std::vector<size_t>& lev, size_t* done);
 
 int add_rows(Graph* g, const uint64_t* ids, uint64_t first_id, const float* rows, size_t n, size_t dim, const long* levels, long level1) {
     if (n == 0) return VDB_OK;
@@ -337,7 +364,26 @@ int add_rows(Graph* g, const uint64_t* ids, uint64_t first_id, const float* rows
         rowv[i] = vdb_internal::row_of(g->flat, ids ? ids[i] : first_id + i);
         if (rowv[i] == 0xffffffffu) { rollback_after((size_t)-1); return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "row was not stored (the same id twice in one batch?)"); }
     }
-    // ---- distances ahead of the walks: chunk c's scan = the chunk's vectors (16 per launch) against device rows
+    // levels in insert order (graph.rs:118-123): drawn here, so that the walks that run AHEAD of the inserts know them.  When
+    // insert i fails, the reference has drawn i + 1 levels: the generator is put back to that point.
+    std::vector<size_t> lev(n);
+    std::vector<uint64_t> rng_after(n);
+    const uint64_t rng0 = g->rng;
+    for (size_t i = 0; i < n; ++i) {
+        const long li = levels ? levels[i] : level1;
+        lev[i] = li >= 0 ? std::min<size_t>((size_t)li, g->max_layers - 1) : level_from_unit(g, next_unit(g));
+        rng_after[i] = g->rng;
+    }
+    auto fail_at = [&](size_t i_fail, int code) { g->rng = i_fail < n ? rng_after[i_fail] : rng0; rollback_after(i_fail); return code; };
+    size_t done = 0;
+    // ---- the frontier-only build: a device walk per insert evaluates what search_layer asks for, the host replays (below)
+    if (g->spec_build && !g->host_only && n >= 32 && walks_supported(g)) {
+        rc = build_speculative(g, ids, first_id, n, rowv, lev, &done);
+        if (rc) return fail_at(done, rc);
+        return VDB_OK;
+    }
+    // ---- the row-scan build (single adds, small batches, shapes the walk kernel does not take): distances ahead of the walks --
+    // chunk c's scan = the chunk's vectors (16 per launch) against device rows
     // [0, last row of the chunk), written by the kernel into one of two mapped host matrices; chunk c+1's scan is enqueued
     // before the host walks chunk c, so the passes over the rows and their transfer hide behind the sequential walks.
     constexpr size_t CHUNK = 128;
@@ -375,16 +421,21 @@ int add_rows(Graph* g, const uint64_t* ids, uint64_t first_id, const float* rows
         return VDB_OK;
     };
     auto drain = [&]() { (void)hipStreamSynchronize(g->scan_stream); };
-    if ((rc = enqueue_scan(0))) { drain(); rollback_after((size_t)-1); return rc; }
+    if ((rc = enqueue_scan(0))) { drain(); return fail_at((size_t)-1, rc); }
     for (size_t c = 0; c < n_chunks; ++c) {
-        if (c + 1 < n_chunks && (rc = enqueue_scan(c + 1))) { drain(); rollback_after(c * CHUNK - 1); return rc; }
-        if (hipEventSynchronize(g->scan_ev[c & 1]) != hipSuccess) { drain(); rollback_after(c * CHUNK - 1); return vdb_internal::set_error(VDB_ERR_DEVICE, "scan failed"); }
+        if (c + 1 < n_chunks && (rc = enqueue_scan(c + 1))) { drain(); return fail_at(c * CHUNK - 1, rc); }
+        if (hipEventSynchronize(g->scan_ev[c & 1]) != hipSuccess) { drain(); return fail_at(c * CHUNK - 1, vdb_internal::set_error(VDB_ERR_DEVICE, "scan failed")); }
         const size_t c0 = c * CHUNK, nc = std::min(CHUNK, n - c0);
         for (size_t i = 0; i < nc; ++i) {
             const uint64_t id = ids ? ids[c0 + i] : first_id + c0 + i;
             // every distance this insert can ask for: the new vector against the rows stored before it
             const float* scan = g->h_scan[c & 1] + i * g->scan_ld;
-            if ((rc = insert_node(g, id, rowv[c0 + i], levels ? levels[c0 + i] : level1, scan))) { drain(); rollback_after(c0 + i); return rc; }
+            auto fetch = [&](const std::vector<uint64_t>& pend, std::vector<float>& d) -> int {
+                for (size_t t = 0; t < pend.size(); ++t) d[t] = scan[g->nodes[pend[t]].row];
+                return VDB_OK;
+            };
+            g->bstats[7]++;
+            if ((rc = insert_node(g, id, rowv[c0 + i], lev[c0 + i], fetch))) { drain(); return fail_at(c0 + i, rc); }
         }
     }
     return VDB_OK;
@@ -444,6 +495,7 @@ int vdb_hnsw_remove(vdb_hnsw_index* g, uint64_t id) {             // graph.rs:34
     std::lock_guard<std::mutex> lk(g->mu);
     if (!g->node(id)) return VDB_OK;
     g->graph_version++;
+    g->mirror_full = true;                                         // lists that still name the node need its row cleared: rebuilt as a whole
     Node gone = std::move(g->nodes[id]);
     g->nodes[id] = Node();
     for (size_t l = 0; l < gone.nbr.size(); ++l)
@@ -588,36 +640,107 @@ void free_mirror(vdb_hnsw_index* g) {
     if (g->d_out_dists) { (void)hipFree(g->d_out_dists); g->d_out_dists = nullptr; }
     g->out_cap = g->out_nq_cap = 0;
     g->mirror_version = 0;
+    g->mirror_full = true; g->cap_ids = g->cap_upper = 0;
+    for (void* hp : {(void*)g->h_stage, (void*)g->h_wq, (void*)g->h_rec_cnt, (void*)g->h_rec_row, (void*)g->h_rec_d}) if (hp) (void)hipHostFree(hp);
+    g->h_stage = nullptr; g->stage_words = 0; g->h_wq = nullptr; g->h_rec_cnt = nullptr; g->h_rec_row = nullptr; g->h_rec_d = nullptr;
 }
 
 // Mirrors the graph into HBM (kernels.h HnswSearchParams): per node id its device row (0xffffffff = absent), level,
-// layer-0 list, and the offset of its upper-layer lists in a pooled array.
-int upload_mirror(vdb_hnsw_index* g, hipStream_t s) {
-    if (g->mirror_version == g->graph_version) return VDB_OK;
+// layer-0 list (stride m_max0) and the offset of its upper-layer lists (stride m) in a pooled array; every list entry carries
+// the device row of the neighbour beside its id.  A FULL rebuild allocates capacity beyond the present graph (reserve_*); after
+// it, inserts are mirrored INCREMENTALLY: the nodes whose lists changed (mark_dirty) are packed into mapped staging memory and
+// scattered by one small kernel -- a bulk build brings the mirror up to date once per chunk of inserts, not once per graph.
+int sync_mirror(vdb_hnsw_index* g, hipStream_t s, size_t reserve_ids, size_t reserve_upper) {
     const uint32_t n = (uint32_t)g->nodes.size();
-    uint32_t max0 = 1, maxU = 1, n_upper = 0;
-    for (const Node& nd : g->nodes) {
-        if (!nd.present) continue;
-        max0 = std::max<uint32_t>(max0, (uint32_t)nd.nbr[0].size());
-        for (size_t l = 1; l < nd.nbr.size(); ++l) maxU = std::max<uint32_t>(maxU, (uint32_t)nd.nbr[l].size());
-        n_upper += nd.level;
-    }
-    std::vector<uint32_t> row_of(n, 0xffffffffu), level(n, 0), cnt0(n, 0), up_off(n, 0), nbr0((size_t)n * max0, 0xffffffffu);
-    std::vector<uint32_t> nbrU((size_t)std::max<uint32_t>(n_upper, 1) * maxU, 0xffffffffu), cntU(std::max<uint32_t>(n_upper, 1), 0);
-    std::vector<uint32_t> nbr0_row(nbr0.size(), 0xffffffffu), nbrU_row(nbrU.size(), 0xffffffffu);
+    const uint32_t stride0 = (uint32_t)g->m_max0, strideU = (uint32_t)g->m;
     auto row_now = [&](uint64_t x) -> uint32_t { const Node* t = g->node(x); return t ? t->row : 0xffffffffu; };
+    // upper-list offsets of nodes that do not have one yet (new nodes of level >= 1)
+    bool full = g->mirror_full || !g->d_row_of || n > g->cap_ids || stride0 != g->stride0 || strideU != g->strideU;
+    if (!full) {
+        if (g->h_up_off.size() < n) g->h_up_off.resize(n, 0xffffffffu);
+        for (uint32_t id : g->dirty) {
+            const Node& nd = g->nodes[id];
+            if (!nd.present || nd.level == 0 || g->h_up_off[id] != 0xffffffffu) continue;
+            if ((size_t)g->n_upper_used + nd.level > g->cap_upper) { full = true; break; }
+            g->h_up_off[id] = g->n_upper_used;
+            g->n_upper_used += nd.level;
+        }
+    }
+    if (!full) {
+        if (g->dirty.empty()) return VDB_OK;
+        // ---- incremental: records of the dirty nodes
+        size_t nU = 0;
+        for (uint32_t id : g->dirty) if (g->nodes[id].present) nU += g->nodes[id].level;
+        const size_t w0 = 4 + 2 * (size_t)stride0, wU = 1 + 2 * (size_t)strideU;
+        const size_t words = g->dirty.size() * w0 + nU * wU;
+        if (words > g->stage_words) {
+            if (g->h_stage) (void)hipHostFree(g->h_stage);
+            g->h_stage = g->d_stage = nullptr; g->stage_words = 0;
+            const size_t cap = words + words / 2 + 4096;
+            HN_TRY(hipHostMalloc((void**)&g->h_stage, cap * 4, hipHostMallocMapped));
+            HN_TRY(hipHostGetDevicePointer((void**)&g->d_stage, g->h_stage, 0));
+            g->stage_words = cap;
+        }
+        uint32_t* r0 = g->h_stage;
+        uint32_t* rU = g->h_stage + g->dirty.size() * w0;
+        uint32_t cU = 0;
+        for (size_t t = 0; t < g->dirty.size(); ++t) {
+            const uint32_t id = g->dirty[t];
+            const Node& nd = g->nodes[id];
+            uint32_t* r = r0 + t * w0;
+            r[0] = id; r[1] = nd.present ? nd.row : 0xffffffffu; r[2] = nd.present ? nd.level : 0u;
+            r[3] = nd.present && nd.level ? g->h_up_off[id] : 0u;
+            for (uint32_t i = 0; i < stride0; ++i) {
+                const bool in = nd.present && i < nd.nbr[0].size();
+                r[4 + i] = in ? (uint32_t)nd.nbr[0][i] : 0xffffffffu;
+                r[4 + stride0 + i] = in ? row_now(nd.nbr[0][i]) : 0xffffffffu;
+            }
+            if (nd.present)
+                for (size_t l = 1; l < nd.nbr.size(); ++l) {
+                    uint32_t* u = rU + (size_t)cU++ * wU;
+                    u[0] = g->h_up_off[id] + (uint32_t)(l - 1);
+                    for (uint32_t i = 0; i < strideU; ++i) {
+                        const bool in = i < nd.nbr[l].size();
+                        u[1 + i] = in ? (uint32_t)nd.nbr[l][i] : 0xffffffffu;
+                        u[1 + strideU + i] = in ? row_now(nd.nbr[l][i]) : 0xffffffffu;
+                    }
+                }
+            g->dirty_flag[id] = 0;
+        }
+        vdb::HnswScatterParams sp{g->d_stage, (uint32_t)g->dirty.size(), g->d_stage + g->dirty.size() * w0, cU,
+                                  g->d_row_of, g->d_level, g->d_up_off, g->d_nbr0, g->d_nbr0_row, stride0, g->d_nbrU, g->d_nbrU_row, strideU};
+        vdb::launch_hnsw_scatter(sp, s);
+        HN_TRY(hipGetLastError());
+        HN_TRY(hipStreamSynchronize(s));                               // the staging memory is reused by the next sync
+        g->dirty.clear();
+        g->mirror_ids = n;
+        g->mirror_version = g->graph_version;
+        return VDB_OK;
+    }
+    // ---- full rebuild, with room to grow
+    uint32_t n_upper = 0;
+    for (const Node& nd : g->nodes) if (nd.present) n_upper += nd.level;
+    const uint32_t cap_ids = (uint32_t)std::min<size_t>(0xfffffff0ull, std::max<size_t>({(size_t)n + n / 4 + 1024, reserve_ids, (size_t)1}));
+    const uint32_t cap_up = (uint32_t)std::min<size_t>(0xfffffff0ull, std::max<size_t>({(size_t)n_upper + n_upper / 4 + 1024, reserve_upper, (size_t)1}));
+    std::vector<uint32_t> row_of(cap_ids, 0xffffffffu), level(cap_ids, 0), up_off(cap_ids, 0), nbr0((size_t)cap_ids * stride0, 0xffffffffu);
+    std::vector<uint32_t> nbrU((size_t)cap_up * strideU, 0xffffffffu);
+    std::vector<uint32_t> nbr0_row(nbr0.size(), 0xffffffffu), nbrU_row(nbrU.size(), 0xffffffffu);
+    g->h_up_off.assign(n, 0xffffffffu);
     uint32_t off = 0;
     for (uint32_t id = 0; id < n; ++id) {
         const Node& nd = g->nodes[id];
         if (!nd.present) continue;
-        row_of[id] = nd.row; level[id] = nd.level; cnt0[id] = (uint32_t)nd.nbr[0].size(); up_off[id] = off;
-        for (size_t i = 0; i < nd.nbr[0].size(); ++i) { nbr0[(size_t)id * max0 + i] = (uint32_t)nd.nbr[0][i]; nbr0_row[(size_t)id * max0 + i] = row_now(nd.nbr[0][i]); }
+        if (nd.nbr[0].size() > stride0) return vdb_internal::set_error(VDB_ERR_DEVICE, "internal error: a layer-0 list exceeds m_max0");
+        row_of[id] = nd.row; level[id] = nd.level; up_off[id] = off;
+        if (nd.level) g->h_up_off[id] = off;
+        for (size_t i = 0; i < nd.nbr[0].size(); ++i) { nbr0[(size_t)id * stride0 + i] = (uint32_t)nd.nbr[0][i]; nbr0_row[(size_t)id * stride0 + i] = row_now(nd.nbr[0][i]); }
         for (size_t l = 1; l < nd.nbr.size(); ++l) {
-            cntU[off + l - 1] = (uint32_t)nd.nbr[l].size();
-            for (size_t i = 0; i < nd.nbr[l].size(); ++i) { nbrU[(size_t)(off + l - 1) * maxU + i] = (uint32_t)nd.nbr[l][i]; nbrU_row[(size_t)(off + l - 1) * maxU + i] = row_now(nd.nbr[l][i]); }
+            if (nd.nbr[l].size() > strideU) return vdb_internal::set_error(VDB_ERR_DEVICE, "internal error: an upper list exceeds m");
+            for (size_t i = 0; i < nd.nbr[l].size(); ++i) { nbrU[(size_t)(off + l - 1) * strideU + i] = (uint32_t)nd.nbr[l][i]; nbrU_row[(size_t)(off + l - 1) * strideU + i] = row_now(nd.nbr[l][i]); }
         }
         off += nd.level;
     }
+    g->n_upper_used = off;
     for (uint32_t** p : {&g->d_row_of, &g->d_level, &g->d_nbr0, &g->d_cnt0, &g->d_up_off, &g->d_nbrU, &g->d_cntU, &g->d_nbr0_row, &g->d_nbrU_row})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     auto up = [&](uint32_t** dst, const std::vector<uint32_t>& v) -> int {
@@ -626,13 +749,166 @@ int upload_mirror(vdb_hnsw_index* g, hipStream_t s) {
         return VDB_OK;
     };
     int rc;
-    if ((rc = up(&g->d_row_of, row_of)) || (rc = up(&g->d_level, level)) || (rc = up(&g->d_nbr0, nbr0)) || (rc = up(&g->d_cnt0, cnt0)) ||
-        (rc = up(&g->d_up_off, up_off)) || (rc = up(&g->d_nbrU, nbrU)) || (rc = up(&g->d_cntU, cntU)) ||
+    if ((rc = up(&g->d_row_of, row_of)) || (rc = up(&g->d_level, level)) || (rc = up(&g->d_nbr0, nbr0)) ||
+        (rc = up(&g->d_up_off, up_off)) || (rc = up(&g->d_nbrU, nbrU)) ||
         (rc = up(&g->d_nbr0_row, nbr0_row)) || (rc = up(&g->d_nbrU_row, nbrU_row)))
         return rc;
     HN_TRY(hipStreamSynchronize(s));                                   // the staging vectors go out of scope
-    g->mirror_ids = n; g->stride0 = max0; g->strideU = maxU; g->max_list = std::max(max0, maxU);
+    g->cap_ids = cap_ids; g->cap_upper = cap_up;
+    g->mirror_ids = n; g->stride0 = stride0; g->strideU = strideU; g->max_list = std::max(stride0, strideU);
     g->mirror_version = g->graph_version;
+    g->mirror_full = false;
+    for (uint32_t id : g->dirty) if (id < g->dirty_flag.size()) g->dirty_flag[id] = 0;
+    g->dirty.clear();
+    return VDB_OK;
+}
+int upload_mirror(vdb_hnsw_index* g, hipStream_t s) {
+    if (g->mirror_version == g->graph_version && !g->mirror_full) return VDB_OK;
+    return sync_mirror(g, s, 0, 0);
+}
+
+bool walks_supported(const Graph* g) {
+    return g->nodes.size() < 0xfffffff0ull &&
+           vdb::hnsw_search_supported((uint32_t)g->dim, (uint32_t)std::min<size_t>(g->ef_construction, 0xffffffu), 1u, (uint32_t)std::max(g->m_max0, g->m) + 1);
+}
+
+// ------------------------------------------------------------------ the frontier-only build
+// Round 2 answered every distance of an insert from a scan of ALL stored rows against the new vector: N^2 / 2 distances for N
+// inserts (5.1e11 at 1M x 768), 70x what the reference's algorithm asks for -- search_layer evaluates only the neighbours of the
+// nodes it expands (graph.rs:155, :182; ~3-7 thousand per insert).  Inserts are sequential by definition, and a GPU round trip
+// per expansion is 8 ms per insert, so the scan was the way to have no round trip at all.  This build has none either, and
+// evaluates only frontiers:
+//   per chunk of WALKS inserts, ONE launch of the device-resident walk (kernels_hnsw.hip, insert mode) runs every insert's
+//   own walk -- greedy descent above its level, search_layer(ef_construction) at and below -- on the graph AS OF THE CHUNK'S
+//   START, and records every (row, distance) it evaluates into mapped host memory; one more launch gives the distances between
+//   the chunk's own vectors.  Then the host replays the inserts IN ORDER with the reference's algorithm, operation by operation,
+//   on the real graph: a distance is looked up in that insert's record (or the in-chunk matrix).  The real walk differs from
+//   the speculative one only where an earlier insert of the same chunk changed a list on its way; a distance it then needs and
+//   the record does not hold is a MISS, evaluated on the GPU at once (one small launch per expansion with misses).
+// The graph is the sequential one by construction -- the replay IS the reference's insert, speculation only decides which
+// distances are already there.  (tests/test_gpu_hnsw.py: node for node equal to the CPU restatement.)
+constexpr uint32_t WALKS = 256, REC_CAP = 8192;
+
+int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n, const std::vector<uint32_t>& rowv,
+                      const std::vector<size_t>& lev, size_t* done) {
+    int rc;
+    *done = (size_t)-1;
+    vdb_internal::DeviceView dv;
+    if ((rc = vdb_internal::device_view(g->flat, &dv))) return rc;
+    hipStream_t s = (hipStream_t)dv.stream;
+    if (!g->h_wq) {
+        HN_TRY(hipHostMalloc((void**)&g->h_wq, 2 * WALKS * 4, hipHostMallocMapped));
+        HN_TRY(hipHostGetDevicePointer((void**)&g->d_wq, g->h_wq, 0));
+        HN_TRY(hipHostMalloc((void**)&g->h_rec_cnt, WALKS * 4, hipHostMallocMapped));
+        HN_TRY(hipHostGetDevicePointer((void**)&g->d_rec_cnt, g->h_rec_cnt, 0));
+        HN_TRY(hipHostMalloc((void**)&g->h_rec_row, (size_t)WALKS * REC_CAP * 4, hipHostMallocMapped));
+        HN_TRY(hipHostGetDevicePointer((void**)&g->d_rec_row, g->h_rec_row, 0));
+        HN_TRY(hipHostMalloc((void**)&g->h_rec_d, (size_t)WALKS * REC_CAP * 4, hipHostMallocMapped));
+        HN_TRY(hipHostGetDevicePointer((void**)&g->d_rec_d, g->h_rec_d, 0));
+    }
+    if (!g->d_fail || g->out_nq_cap < WALKS) {
+        if (g->d_fail) (void)hipFree(g->d_fail);
+        if (g->d_out_counts) (void)hipFree(g->d_out_counts);
+        g->d_fail = g->d_out_counts = nullptr;
+        HN_TRY(hipMalloc((void**)&g->d_fail, WALKS * 4));
+        HN_TRY(hipMalloc((void**)&g->d_out_counts, WALKS * 4));
+        if (g->d_out_ids) { (void)hipFree(g->d_out_ids); g->d_out_ids = nullptr; }
+        if (g->d_out_dists) { (void)hipFree(g->d_out_dists); g->d_out_dists = nullptr; }
+        g->out_cap = 0; g->out_nq_cap = WALKS;
+    }
+    // room in the mirror for the whole batch: ids up to the largest of the batch, upper lists for its levels
+    size_t max_id = 0, up_need = 0;
+    for (size_t i = 0; i < n; ++i) { max_id = std::max<size_t>(max_id, ids ? ids[i] : first_id + i); up_need += lev[i]; }
+    size_t up_have = 0;
+    for (const Node& nd : g->nodes) if (nd.present) up_have += nd.level;
+    if (max_id + 1 > g->cap_ids || up_have + up_need > g->cap_upper) g->mirror_full = true;
+    std::vector<uint32_t> tab_row(16384), fetch_miss_idx, miss_a, miss_b;
+    std::vector<float> tab_d(16384), tri, miss_d;
+    std::unordered_map<uint32_t, uint32_t> in_chunk;
+    std::vector<uint32_t> pa, pb;
+    for (size_t c0 = 0; c0 < n; c0 += WALKS) {
+        const size_t nc = std::min<size_t>(WALKS, n - c0);
+        // ---- the mirror as of the chunk's start; the walks of the chunk on it
+        if ((rc = sync_mirror(g, s, max_id + 1, up_have + up_need))) return rc;
+        const bool have_graph = g->has_ep;
+        if (have_graph) {
+            for (size_t i = 0; i < nc; ++i) { g->h_wq[i] = rowv[c0 + i]; g->h_wq[WALKS + i] = (uint32_t)lev[c0 + i]; }
+            vdb::HnswSearchParams hp{};
+            hp.rows = dv.rows; hp.ld = dv.ld; hp.dim = dv.dim; hp.nd = dv.nd; hp.metric = dv.metric; hp.qp = nullptr; hp.qnorm = nullptr;
+            hp.row_of = g->d_row_of; hp.level = g->d_level; hp.n_ids = g->mirror_ids; hp.nbr0 = g->d_nbr0; hp.nbr0_row = g->d_nbr0_row; hp.cnt0 = nullptr;
+            hp.stride0 = g->stride0; hp.up_off = g->d_up_off; hp.nbrU = g->d_nbrU; hp.nbrU_row = g->d_nbrU_row; hp.cntU = nullptr; hp.strideU = g->strideU;
+            hp.entry_point = (uint32_t)g->ep; hp.max_level = (uint32_t)g->max_level; hp.ef = (uint32_t)g->ef_construction; hp.k = 0;
+            hp.out_ids = nullptr; hp.out_dists = nullptr; hp.out_counts = g->d_out_counts; hp.fail = g->d_fail; hp.status = dv.status;
+            hp.qrow = g->d_wq; hp.qlevel = g->d_wq + WALKS;
+            hp.rec_row = g->d_rec_row; hp.rec_d = g->d_rec_d; hp.rec_cnt = g->d_rec_cnt; hp.rec_cap = REC_CAP; hp.rec_zero_mark = vdb_internal::ZERO_NORM_MARK;
+            vdb::launch_hnsw_search(hp, (uint32_t)nc, s);
+            HN_TRY(hipGetLastError());
+            g->stats[1]++;
+        }
+        // ---- distances between the chunk's own vectors: pair (i, j), j < i, at tri[i (i - 1) / 2 + j]
+        in_chunk.clear();
+        uint32_t row_lo = 0xffffffffu, row_hi = 0;
+        for (size_t i = 0; i < nc; ++i) { in_chunk[rowv[c0 + i]] = (uint32_t)i; row_lo = std::min(row_lo, rowv[c0 + i]); row_hi = std::max(row_hi, rowv[c0 + i]); }
+        pa.clear(); pb.clear();
+        for (size_t i = 1; i < nc; ++i) for (size_t j = 0; j < i; ++j) { pa.push_back(rowv[c0 + i]); pb.push_back(rowv[c0 + j]); }
+        tri.resize(pa.size());
+        if (!pa.empty()) {
+            if ((rc = vdb_internal::rows_eval(g->flat, pa.data(), pb.data(), pa.size(), tri.data()))) return rc;   // (synchronises the stream: the walks are done too)
+            g->stats[0] += pa.size(); g->stats[1]++; g->bstats[2] += pa.size();
+        } else HN_TRY(hipStreamSynchronize(s));
+        if (have_graph)
+            for (size_t i = 0; i < nc; ++i) {
+                g->bstats[1] += std::min<uint32_t>(g->h_rec_cnt[i], REC_CAP);
+                g->stats[0] += std::min<uint32_t>(g->h_rec_cnt[i], REC_CAP);
+                if (g->h_rec_cnt[i] > REC_CAP) g->bstats[5]++;
+            }
+        // ---- the authoritative replay, insert by insert
+        for (size_t i = 0; i < nc; ++i) {
+            const uint64_t id = ids ? ids[c0 + i] : first_id + c0 + i;
+            const uint32_t my_row = rowv[c0 + i];
+            // this insert's record as a hash table row -> distance (16384 slots, at most 8192 entries)
+            std::fill(tab_row.begin(), tab_row.end(), 0xffffffffu);
+            const uint32_t cnt = have_graph ? std::min<uint32_t>(g->h_rec_cnt[i], REC_CAP) : 0u;
+            const uint32_t* rr = g->h_rec_row + (size_t)i * REC_CAP;
+            const float* rd = g->h_rec_d + (size_t)i * REC_CAP;
+            for (uint32_t t = 0; t < cnt; ++t) {
+                uint32_t h = (rr[t] * 0x9e3779b1u) >> 18;
+                while (tab_row[h] != 0xffffffffu && tab_row[h] != rr[t]) h = (h + 1) & 16383u;
+                tab_row[h] = rr[t]; tab_d[h] = rd[t];
+            }
+            auto fetch = [&](const std::vector<uint64_t>& pend, std::vector<float>& d) -> int {
+                fetch_miss_idx.clear();
+                for (size_t t = 0; t < pend.size(); ++t) {
+                    const uint32_t row = g->nodes[pend[t]].row;
+                    auto ic = (row >= row_lo && row <= row_hi) ? in_chunk.find(row) : in_chunk.end();
+                    if (ic != in_chunk.end()) {                          // a vector of this chunk, inserted before this one
+                        const uint32_t a = (uint32_t)i, b = ic->second;
+                        d[t] = a > b ? tri[(size_t)a * (a - 1) / 2 + b] : tri[(size_t)b * (b - 1) / 2 + a];
+                        continue;
+                    }
+                    uint32_t h = (row * 0x9e3779b1u) >> 18;
+                    while (tab_row[h] != 0xffffffffu && tab_row[h] != row) h = (h + 1) & 16383u;
+                    if (tab_row[h] == row) d[t] = tab_d[h];
+                    else fetch_miss_idx.push_back((uint32_t)t);
+                }
+                if (!fetch_miss_idx.empty()) {                          // the real walk left the speculative one: evaluate now
+                    miss_a.assign(fetch_miss_idx.size(), my_row);
+                    miss_b.resize(fetch_miss_idx.size());
+                    miss_d.resize(fetch_miss_idx.size());
+                    for (size_t t = 0; t < fetch_miss_idx.size(); ++t) miss_b[t] = g->nodes[pend[fetch_miss_idx[t]]].row;
+                    int r2 = vdb_internal::rows_eval(g->flat, miss_a.data(), miss_b.data(), miss_a.size(), miss_d.data());
+                    if (r2) return r2;
+                    for (size_t t = 0; t < fetch_miss_idx.size(); ++t) d[fetch_miss_idx[t]] = miss_d[t];
+                    g->stats[0] += miss_a.size(); g->stats[1]++;
+                    g->bstats[3] += miss_a.size(); g->bstats[4]++;
+                }
+                return VDB_OK;
+            };
+            g->bstats[0]++;
+            if ((rc = insert_node(g, id, my_row, lev[c0 + i], fetch))) { *done = c0 + i; return rc; }
+            *done = c0 + i;
+        }
+    }
     return VDB_OK;
 }
 
@@ -767,6 +1043,21 @@ int vdb_hnsw_entry_point(const vdb_hnsw_index* g, uint64_t* id, size_t* max_leve
     if (id) *id = g->ep;
     if (max_level) *max_level = g->max_level;
     return g->has_ep ? 1 : 0;
+    });
+}
+int vdb_hnsw_set_build(vdb_hnsw_index* g, int frontier_only) {
+    return guarded([&]() -> int {
+    if (!g) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null handle");
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->spec_build = frontier_only != 0;
+    return VDB_OK;
+    });
+}
+int vdb_hnsw_build_stats(const vdb_hnsw_index* g, uint64_t out[8]) {
+    return guarded([&]() -> int {
+    if (!g || !out) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    memcpy(out, g->bstats, sizeof(g->bstats));
+    return VDB_OK;
     });
 }
 int vdb_hnsw_stats(const vdb_hnsw_index* g, uint64_t out[6]) {

@@ -151,3 +151,16 @@ class GpuHnswIndex(Index):
         self._L.vdb_hnsw_stats(self._h, out)
         return dict(zip(["gpu_distances", "gpu_launches", "last_search_rounds", "last_search_distances", "device_queries",
                          "host_redone"], [int(v) for v in out]))
+
+    def set_build(self, frontier_only=True):
+        """Bulk inserts: True (default) = device walks evaluate only what search_layer asks for, the host replays the inserts in
+        order; False = the row-scan build (every stored row against every new vector).  The graph is the same."""
+        rc = self._L.vdb_hnsw_set_build(self._h, 1 if frontier_only else 0)
+        if rc:
+            _raise(rc)
+
+    def build_stats(self):
+        out = (ctypes.c_uint64 * 8)()
+        self._L.vdb_hnsw_build_stats(self._h, out)
+        return dict(zip(["frontier_inserts", "walk_distances", "in_chunk_distances", "miss_distances", "miss_round_trips",
+                         "record_overflows", "reference_distances", "scan_inserts"], [int(v) for v in out]))
