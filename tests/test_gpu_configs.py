@@ -195,3 +195,45 @@ def test_c5_hnsw_at_768_dimensions_against_the_cpu_restatement(vdb):
     rec = float(np.mean([oracle.recall(fi[b], gi[b, :gc[b]]) for b in range(B)]))
     print(f"\n[c5] HNSW 30k x 768 m=16 ef=200: recall@10 vs exact = {rec:.3f}")
     assert rec > 0.3
+
+
+def test_c5_hnsw_200k_x_768_frontier_only_build(vdb):
+    """BASELINE config 5's parameters (m = 16, ef_construction = 200, ef_search = 200, 768 dimensions) at 200,000 rows -- a size
+    the CPU restatement cannot follow inside a test suite (hours), so the checks are size-independent: the build evaluates about
+    what the reference's algorithm consumes (not N^2 / 2 = 2e10), every list respects the reference's caps (graph.rs:40,
+    :207-241), the levels follow the seeded stream, the device-resident search equals the host traversal of the same graph bit
+    for bit."""
+    import time
+    n, d, m, efc, efs, B, k = 200_000, 768, 16, 200, 200, 64, 10
+    rng = np.random.default_rng(77)
+    rows = rng.random((n, d), dtype=np.float32)
+    g = vdb.GpuHnswIndex(vdb.DistanceMetric.Euclidean, vdb.HnswParams.new(m, efc, 50), seed=5)
+    t0 = time.perf_counter()
+    for c0 in range(0, n, 50_000):
+        g.build_batch((np.arange(c0, c0 + 50_000, dtype=np.uint64), rows[c0:c0 + 50_000]))
+    t_build = time.perf_counter() - t0
+    bs = g.build_stats()
+    gpu = bs["walk_distances"] + bs["in_chunk_distances"] + bs["miss_distances"]
+    print(f"\n[c5] HNSW 200k x 768 build {t_build:.1f} s; GPU distances {gpu:.3e} = {gpu / bs['reference_distances']:.3f} x the reference "
+          f"algorithm's {bs['reference_distances']:.3e} (row scans: {n * (n - 1) / 2:.1e}); misses {bs['miss_round_trips']}")
+    assert bs["frontier_inserts"] == n and bs["scan_inserts"] == 0, bs
+    assert gpu <= 1.5 * bs["reference_distances"] and gpu < 0.1 * n * (n - 1) / 2, bs
+    assert g.len() == n
+    ep, max_level = g.entry_point()
+    assert g.level(ep) == max_level
+    for i in list(range(0, n, 4001)) + [ep]:
+        lv = g.level(i)
+        for l in range(lv + 1):
+            nb = g.neighbors(i, l)
+            assert len(nb) <= (2 * m if l == 0 else m) and len(set(nb)) == len(nb) and i not in nb, (i, l)
+            assert all(g.level(int(x)) >= l for x in nb), (i, l)
+    q = rng.random((B, d), dtype=np.float32)
+    di, dd, dc = g.search_batch_arrays(q, k, efs)
+    assert g.stats()["device_queries"] == B and g.stats()["host_redone"] == 0
+    g.set_traversal(host_only=True)
+    hi, hd, hc = g.search_batch_arrays(q[:16], k, efs)
+    g.set_traversal(host_only=False)
+    assert np.array_equal(hc, dc[:16]) and np.array_equal(hi, di[:16]) and np.array_equal(hd.view(np.uint32), dd[:16].view(np.uint32))
+    assert np.all(dd[:, 1:] >= dd[:, :-1]) and np.all(dc == k)
+    # (no self-query assertion: on uniform 768-dimensional data the reference's simple neighbour selection reaches recall@10 of
+    # ~0.3 at this size -- DESIGN.md 11 -- and a walk from the entry point need not arrive at a stored row that is the query)
