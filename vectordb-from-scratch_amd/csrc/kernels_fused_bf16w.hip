@@ -39,7 +39,7 @@ constexpr int A_BYTES = TR * A_ROWB;             // 16 KB
 constexpr int B_BYTES = TQ * B_ROWB;             // 32 KB
 constexpr int BQ_BYTES = QB * B_ROWB;            // 16 KB: one block's query image of a K stage in global memory
 constexpr int STAGE_BYTES = A_BYTES + B_BYTES;   // 48 KB
-constexpr int MT = 4, QT = 2;                    // MFMA tiles per wave: 4 x 32 rows, 2 x 32 queries
+constexpr int MT = 2, QT = 4;                    // MFMA tiles per wave: 2 x 32 rows, 4 x 32 queries
 
 #ifdef VDB_DIAG
 constexpr bool kDiag = true;                     // ablate bits 32 / 64 below exist in the diagnostics build only
@@ -62,7 +62,7 @@ __device__ __forceinline__ bf16x8 cvt8(const float4& lo, const float4& hi) {
 // MARGIN (Dot / Euclid): the kernel ranks by the LOWER-BOUND score fma(-g_q, margin_row, score) -- see FusedBf16Params.
 template <bool MARGIN>
 __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
-    constexpr bool SAMPLE = false;
+
     // three DISTINCT LDS objects, each access names its image at compile time (see kernels_fused_dma3.hip)
     __shared__ __attribute__((aligned(16))) char sImg0[STAGE_BYTES];
     __shared__ __attribute__((aligned(16))) char sImg1[STAGE_BYTES];
@@ -74,11 +74,14 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
     __shared__ __attribute__((aligned(16))) uint32_t sMaskW[2 * TR];
     __shared__ __attribute__((aligned(16))) float sMarg[MARGIN ? 2 * TR : 4];   // per-row error margin of a tile (same double buffering)
     __shared__ float sG[MARGIN ? TQ : 1];                                        // g_q of the 512 queries (read in the epilogue only)
+    __shared__ float sThr[TQ];                                                   // their thresholds (likewise)
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr uint32_t wr = 0;                                          // every wave covers all 128 rows of the tile ...
-    const uint32_t wq = w;                                              // ... for its own 64 of the 512 queries
+    // wave tile = 64 rows x 128 queries: per K stage a wave reads 8 KB of row fragments + 8 KB of query fragments from LDS -- the
+    // split that minimises fragment bytes for 8192 outputs when a row costs 128 B (f32) and a query 64 B (bf16); 128 rows x 64
+    // queries (round 3's first version) read 16 + 4 KB and converted twice as many row fragments to bf16
+    const uint32_t wr = w >> 2, wq = w & 3;                             // row half of the 128-row tile, query quarter of the 512 queries
     const uint32_t c = lane & 31, h = lane >> 5;
     const uint32_t ld = p.ld;
     const uint32_t KS = ld / KSTAGE;
@@ -87,67 +90,39 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
     // (sample mode: exactly ONE tile per workgroup, grid = number of sample tiles.  A compile-time tile count lets
     // the compiler drop the next-tile address state; with it the sample instance spilled registers to scratch, and
     // every scratch reload put a vmcnt(0) -- a full drain of the DMA pipeline -- into the stage loop)
-    uint32_t r0 = 0, r1 = 0, ntiles_rt = 0;
-    const uint32_t tile_first = SAMPLE ? blockIdx.x : 0u;
-    constexpr uint32_t tile_step = 0;
-    if (SAMPLE) {
-        ntiles_rt = 1;
-    } else {
-        // WHOLE tiles, dealt round-robin: workgroup w takes tiles w, w + n_wg, ...  (some workgroups run one tile fewer; the
-        // last tiles of the others meet an HBM that is no longer contended).  Round-robin rather than one contiguous range per
-        // workgroup: the 256 streams then walk through ONE window of the matrix together instead of 256 windows 12 MB apart
-        // (tools/read_pattern_probe.hip: 0.465 against 0.471 ms for the DMA traffic of this kernel alone)
-        const uint32_t nblk = (p.n_rows + TR - 1) / TR;
-        r0 = blockIdx.x * TR;
-        r1 = p.n_rows;
-        ntiles_rt = blockIdx.x < nblk ? (nblk - blockIdx.x + p.n_wg - 1) / p.n_wg : 0;
-    }
-    const uint32_t TS = SAMPLE ? TR : p.n_wg * TR;                      // rows between consecutive tiles of this workgroup
-    const uint32_t ntiles = SAMPLE ? 1u : ntiles_rt;
+    // WHOLE tiles, dealt round-robin: workgroup w takes tiles w, w + n_wg, ...  (see kernels_fused_bf16p.hip)
+    const uint32_t nblk = (p.n_rows + TR - 1) / TR;
+    const uint32_t r0 = blockIdx.x * TR, r1 = p.n_rows;
+    const uint32_t ntiles = blockIdx.x < nblk ? (nblk - blockIdx.x + p.n_wg - 1) / p.n_wg : 0;
+    const uint32_t TS = p.n_wg * TR;                                    // rows between consecutive tiles of this workgroup
     // queries of this lane: one column in each of the wave's two 32-query MFMA tiles
-    const uint32_t q_a = wq * 64 + c, q_b = q_a + 32;
-    // (query b = query a + 32: its count and its pool sit 128 sub-pools further -- derived where they are needed, in the rare path
-    // and at the end, instead of being held in two more registers across the stage loop: the kernel is at the 256-VGPR limit, and
-    // a pointer spilled to scratch cost a vmcnt(0) -- a drain of the DMA ring -- at every append)
-    uint64_t* pool_a = nullptr;
-    size_t sub_a = 0;
-    float thr_a = 0.f, thr_b = 0.f;
-    if (!SAMPLE) {
-        // pools: the ordinary workgroup-major pools of the query's 256-query BLOCK (see kernels_fused_bf16p.hip), sub-pools 0 / 1
-        // = lane half (this kernel has no row halves; the counts of sub-pools 2 / 3 are zeroed at the end)
-        const uint32_t blk = q_a >> 8;                                  // q_a and q_b lie in the same block (64-query wave ranges)
-        const size_t cnt_base = (size_t)blk * p.cnt_block_stride;
-        sub_a = cnt_base + ((size_t)blockIdx.x * QB + (q_a & 255u)) * 4 + h;
-        uint64_t* const pool_blk = p.pool + (size_t)blk * p.pool_block_stride;
-        pool_a = pool_blk + (((size_t)blockIdx.x * QB + (q_a & 255u)) * 4 + h) * p.capl;
-        thr_a = p.thr[q_a];
-        thr_b = p.thr[q_b];
-        // consume the two loads here: a first use inside the stage loop would get a compiler-inserted vmcnt(0)
-        // there, i.e. a wait for every DMA in flight, once per tile
-        if (p.ablate & 16u) thr_a = thr_b = -3.0e38f;              // diagnostics: nothing passes the filter (cost of the append path; finite, so that the MARGIN instance's loosened threshold is not inf - inf)
-        asm volatile("" : "+v"(thr_a), "+v"(thr_b));
-    }
-    uint32_t pcnt_a = 0, pcnt_b = 0;
+    const uint32_t q_a = wq * 128 + c;                                  // the lane's queries: q_a + 32 j, j = 0..3 (one column in each of the wave's four 32-query MFMA tiles)
+    // (query j of the lane = query a + 32 j: its count sits 128 j counts and its pool 128 j sub-pools further -- derived where they
+    // are needed, in the rare path and at the end, instead of being held in registers across the stage loop: the kernel is at the
+    // 256-VGPR limit, and a pointer spilled to scratch cost a vmcnt(0) -- a drain of the DMA ring -- at every append; the thresholds
+    // live in LDS for the same reason)
+    // sub-pool r = 2 * row half + lane half of query q (inside its 256-query block), as in kernels_fused_bf16p.hip; recomputed from
+    // the thread index wherever it is needed (the empty asm keeps hipcc from hoisting the result into a register held -- i.e.
+    // spilled -- across the stage loop)
+    auto sub_of = [&](uint32_t jq) -> size_t {
+        uint32_t t_ = threadIdx.x;
+        asm volatile("" : "+v"(t_));
+        const uint32_t l_ = t_ & 63u, w_ = t_ >> 6;
+        const uint32_t q_ = (w_ & 3u) * 128u + (l_ & 31u) + 32u * jq;
+        return ((size_t)blockIdx.x * QB + (q_ & 255u)) * 4 + 2 * (w_ >> 2) + (l_ >> 5);
+    };
+    // the lane's four sub-pool counts, two 16-bit counters per register (saturating; a count above capl means overflow): four
+    // registers' worth of counters were the ones the MARGIN instance spilled, and a scratch access on the append path drains the DMA ring
+    uint32_t pcnt_pk[2] = {0u, 0u};
     // can a score of this launch be NaN at all?  (wave-uniform; decides how the epilogue tests four scores at once)
-    const bool no_nan = !SAMPLE && fused_no_nan(p.scalars, p.qmax_bits, !MARGIN);
+    const bool no_nan = fused_no_nan(p.scalars, p.qmax_bits, !MARGIN);
     if (ntiles == 0) {
-        p.pool_cnt[sub_a] = 0; p.pool_cnt[sub_a + 128] = 0; p.pool_cnt[sub_a + 2] = 0; p.pool_cnt[sub_a + 130] = 0;
+#pragma unroll
+        for (int j = 0; j < QT; ++j) p.pool_cnt[(size_t)(wq >> 1) * p.cnt_block_stride + sub_of(j)] = 0;
         return;
     }
     const uint32_t total = ntiles * KS;
     const uint32_t last_row = p.n_rows - 1;
-    // sample index -> device row.  The S sample positions are spread evenly over the rows ((pos * n) >> shift), and
-    // CONSECUTIVE positions go to DIFFERENT tiles (index j = tile*256 + tile-row sits at position tile-row*tiles + tile):
-    // when near neighbours are stored next to each other (data ordered by cluster) their sample rows then land in
-    // different groups, each contributes its own group minimum, and the threshold stays as tight as on shuffled data
-    // (with consecutive positions in one tile a 500-row cluster was represented by 4 minima, the threshold came from far
-    // rows and thousands of keys overflowed the pools).  Block mode (sample_block != 0, diagnostics): tiles of
-    // contiguous rows.
-    auto sample_row_of = [&](uint32_t j) -> uint32_t {
-        if (p.sample_block) return (j >> 8) * p.sample_block + (j & 255u);
-        const uint32_t pos = (j & 255u) * (p.n_sample >> 8) + (j >> 8);
-        return (uint32_t)(((uint64_t)pos * p.n_rows) >> p.sample_shift);
-    };
     const char* __restrict__ rows_b = reinterpret_cast<const char*>(p.rows);
     const char* __restrict__ bbase = reinterpret_cast<const char*>(p.qb);
 
@@ -238,6 +213,14 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
         // publishes the array
         if (tid < TQ) { float g = p.qg[tid]; asm volatile("" : "+v"(g)); sG[tid] = g; }
     }
+    {
+        // thresholds into LDS: consumed here, so that no ordinary load is pending inside the stage loop (a first use there would
+        // get a compiler-inserted vmcnt(0), i.e. a wait for every DMA in flight, once per tile)
+        float t = p.thr[tid];                                           // NT == TQ
+        if (p.ablate & 16u) t = -3.0e38f;                               // diagnostics: nothing passes the filter (finite, so that the MARGIN instance's loosened threshold is not inf - inf)
+        asm volatile("" : "+v"(t));
+        sThr[tid] = t;
+    }
 
     f32x16 acc[MT][QT];
 #pragma unroll
@@ -249,8 +232,8 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
 
     // fragment read offsets (bytes inside an image)
     const uint32_t swa = (c >> 1) & 7, swb = (c >> 2) & 3;
-    const uint32_t a_row_off = (wr * 128 + c) * A_ROWB;                 // + i*32*A_ROWB
-    const uint32_t b_row_off = A_BYTES + (wq * 64 + c) * B_ROWB;        // + j*32*B_ROWB
+    const uint32_t a_row_off = (wr * 64 + c) * A_ROWB;                  // + i*32*A_ROWB
+    const uint32_t b_row_off = A_BYTES + (wq * 128 + c) * B_ROWB;       // + j*32*B_ROWB
     uint32_t ra[2], rb[2];                                              // [k-step]; the second half chunk of a row fragment is at ra ^ 16
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -303,7 +286,7 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
         const u32x4 raw_ = *reinterpret_cast<const u32x4*>((IMG) + b_row_off + j_ * 32 * B_ROWB + rb[T_]); \
         FB[j_] = __builtin_bit_cast(bf16x8, raw_);                                                     \
     }
-#define VDB_STEP(I_, FA_USE, FB_USE, FA_NEW, IMG_NEW, T_NEW, LOAD_, EXTRA)                             \
+#define VDB_STEP(I_, FA_USE, FB_USE, FA_NEW, IMG_NEW, T_NEW, LOAD_, EX0, EX1, EX2)                     \
     {                                                                                                  \
         float4 lo_, hi_;                                                                               \
         if (LOAD_) {                                                                                   \
@@ -313,14 +296,19 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
         __builtin_amdgcn_sched_barrier(0);                                                             \
         acc[I_][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA_USE[I_], FB_USE[0], acc[I_][0], 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                             \
-        EXTRA                                                                                          \
+        EX0                                                                                            \
         acc[I_][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA_USE[I_], FB_USE[1], acc[I_][1], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        EX1                                                                                            \
+        acc[I_][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA_USE[I_], FB_USE[2], acc[I_][2], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        EX2                                                                                            \
+        acc[I_][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA_USE[I_], FB_USE[3], acc[I_][3], 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                             \
         if (LOAD_) FA_NEW[I_] = cvt8(lo_, hi_);                                                        \
     }
         VDB_READ_B(fb1, img, 1)
-        VDB_STEP(0, fa0, fb0, fa1, img, 1, true, ) VDB_STEP(1, fa0, fb0, fa1, img, 1, true, )
-        VDB_STEP(2, fa0, fb0, fa1, img, 1, true, ) VDB_STEP(3, fa0, fb0, fa1, img, 1, true, )
+        VDB_STEP(0, fa0, fb0, fa1, img, 1, true, , , ) VDB_STEP(1, fa0, fb0, fa1, img, 1, true, , , )
         // publish stage st+1: this wave's pieces of it have landed once at most the 6 pieces of stage st+2 are
         // outstanding; lgkmcnt(0): this wave's fragment reads of stage st are done, so after the barrier the image of
         // stage st is free.  (A bare s_barrier: __syncthreads() carries a fence that hipcc lowers to vmcnt(0).)
@@ -346,10 +334,8 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
     if (do_dma && !(p.ablate & 4u)) { VDB_DMA_OFF(qsrc_, img, lb_, (J_) * 1024); }                     \
     __builtin_amdgcn_sched_barrier(0);
         if (more) VDB_READ_B(fb0, nxt, 0)
-        VDB_STEP(0, fa1, fb1, fa0, nxt, 0, more, VDB_PIECE_A(0) VDB_PIECE_A(1))
-        VDB_STEP(1, fa1, fb1, fa0, nxt, 0, more, VDB_PIECE_B(0) VDB_PIECE_B(1))
-        VDB_STEP(2, fa1, fb1, fa0, nxt, 0, more, VDB_PIECE_B(2))
-        VDB_STEP(3, fa1, fb1, fa0, nxt, 0, more, VDB_PIECE_B(3))
+        VDB_STEP(0, fa1, fb1, fa0, nxt, 0, more, VDB_PIECE_A(0), VDB_PIECE_A(1), VDB_PIECE_B(0))
+        VDB_STEP(1, fa1, fb1, fa0, nxt, 0, more, VDB_PIECE_B(1), VDB_PIECE_B(2), VDB_PIECE_B(3))
 #undef VDB_PIECE_A
 #undef VDB_PIECE_B
 #undef VDB_STEP
@@ -360,54 +346,35 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
             const uint32_t par = tile & 1u;
             // (the constants of this tile were issued at least one counted top-of-stage wait + barrier ago: every
             // stage that issues them either issues 6 row/query pieces after them or is followed by a vmcnt(0) wait)
-            uint32_t tr0;                                               // device row of tile-row 0 (filter mode)
-            uint32_t sj0 = 0;                                           // sample index of tile-row 0 (sample mode)
-            if (SAMPLE) { sj0 = (tile_first + tile * tile_step) * TR; tr0 = 0; }
-            else tr0 = r0 + tile * TS;
-            // eligibility of this wave's 128 rows: two ballots over (in range) & (mask bit of the row)
-            unsigned long long val[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const uint32_t rt = wr * 128 + 64 * m + lane;
-                bool in;
-                uint32_t bit;
-                if (SAMPLE) {
-                    const uint32_t sj = sj0 + rt;
-                    in = sj < p.n_sample;
-                    const uint32_t row = sample_row_of(sj);
-                    bit = row & 31;
-                } else {
-                    in = tr0 + rt < r1;
-                    bit = rt & 31;                                      // tr0 is a multiple of 32
-                }
-                val[m] = __ballot(in && ((sMaskW[par * TR + rt] >> bit) & 1u));
-            }
-            float best_a = __uint_as_float(0x7f800000u), best_b = best_a;   // sample mode: running group minima
-            const float* al = sAlpha + par * TR + wr * 128 + 4 * h;
-            const float* be = sBeta + par * TR + wr * 128 + 4 * h;
+            const uint32_t tr0 = r0 + tile * TS;                        // device row of tile-row 0
+            // eligibility of this wave's 64 rows: one ballot over (in range) & (mask bit of the row)
+            const uint32_t rt_l = wr * 64 + lane;
+            const unsigned long long val = __ballot(tr0 + rt_l < r1 && ((sMaskW[par * TR + rt_l] >> (rt_l & 31)) & 1u));   // tr0 is a multiple of 32
+            const float* al = sAlpha + par * TR + wr * 64 + 4 * h;
+            const float* be = sBeta + par * TR + wr * 64 + 4 * h;
             // MARGIN: the filter is  lb = fma(-g_q, margin_row, score) <= thr.  Since margin_row <= mmax (the largest margin of
-            // this wave's 128 rows), lb <= thr implies score <= thr + g_q mmax =: thp -- so the COMMON path compares the plain
-            // score with a per-tile loosened threshold (two fmas per lane and tile instead of one packed fma and one more LDS
-            // read per pair of elements), and only the rare path computes lb and applies the exact test.  The slack covers
-            // the f32 rounding of thp and of lb, so no row with lb <= thr can fail the pre-test.
-            const float* mg = sMarg + (MARGIN ? par * TR + wr * 128 : 0);
-            float thp_a = thr_a, thp_b = thr_b, ng_a = 0.f, ng_b = 0.f;
+            // this wave's 64 rows), lb <= thr implies score <= thr + g_q mmax =: thp -- so the COMMON path compares the plain
+            // score with a per-tile loosened threshold, and only the rare path computes lb and applies the exact test.  The
+            // slack covers the f32 rounding of thp and of lb, so no row with lb <= thr can fail the pre-test.
+            const float* mg = sMarg + (MARGIN ? par * TR + wr * 64 : 0);
+            float thr_q[QT], thp[QT], ng[QT];
+#pragma unroll
+            for (int jq = 0; jq < QT; ++jq) { thr_q[jq] = sThr[q_a + 32 * jq]; thp[jq] = thr_q[jq]; ng[jq] = 0.f; }
             if (MARGIN) {
-                float mm = fmaxf(mg[2 * lane], mg[2 * lane + 1]);       // +inf margins (norm overflow) open the tile; NaN rows carry NaN scores anyway
+                float mm = mg[lane];                                    // +inf margins (norm overflow) open the tile; NaN rows carry NaN scores anyway
                 for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o));
-                const float ga = sG[q_a], gb = sG[q_b];
-                ng_a = -ga; ng_b = -gb;
-                thp_a = fmaf(ga, mm, thr_a); thp_a += (fabsf(thr_a) + ga * mm) * 6.0e-7f;
-                thp_b = fmaf(gb, mm, thr_b); thp_b += (fabsf(thr_b) + gb * mm) * 6.0e-7f;
+#pragma unroll
+                for (int jq = 0; jq < QT; ++jq) {
+                    const float g = sG[q_a + 32 * jq];
+                    ng[jq] = -g;
+                    thp[jq] = fmaf(g, mm, thr_q[jq]); thp[jq] += (fabsf(thr_q[jq]) + g * mm) * 6.0e-7f;
+                }
             }
-            // Per row block i (32 rows x 2 queries per lane = 4 groups of 4 rows): the COMMON path is branch-free -- scores of the four
-            // groups, the minimum of each group against the (loosened) threshold, the four lane masks OR-ed on the scalar unit --
-            // and ends in ONE not-taken branch per query.  (Until round 3 every group of 4 rows had its own three branches, with the
-            // LDS reads of its constants issued right in front of their use: 48 branch points and 16 exposed LDS round trips per
-            // tile made the epilogue ~5 us per tile, a fifth of the wide kernel's time, although appends are rare; without branches
-            // between the groups the compiler hoists the LDS reads and interleaves the groups.)  Hits are rare (about 0.1 % of the
-            // elements), so the RARE path recomputes the block's scores for its query from the accumulators -- nothing of the
-            // common path has to stay live for it -- and appends what passes the exact test.
+            // Per row block i (32 rows x 4 queries per lane = 4 groups of 4 rows): the COMMON path is branch-free -- scores of the
+            // four groups, the minimum of each group against the (loosened) threshold, the lane masks OR-ed on the scalar unit -- and
+            // ends in ONE not-taken branch per query; one pair of LDS reads (alpha, beta of 4 rows) serves all four queries.  Hits
+            // are rare (about 0.1 % of the elements), so the RARE path recomputes the block's scores for its query from the
+            // accumulators -- nothing of the common path has to stay live for it -- and appends what passes the exact test.
             // v_min_f32 drops a NaN operand and a NaN score must pass (flat_index.rs:62): the minimum test stands alone only when
             // no score of the launch can be NaN (fused_no_nan: every norm within [2^-40, 2^40]); otherwise a NaN-propagating sum of
             // each group is tested as well (inf - inf gives a false alarm, which the exact per-row test of the rare path sorts out).
@@ -430,37 +397,40 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
                 sc_ = fmaf((NG), mg[(I_) * 32 + 8 * (J_) + 4 * h + e_], sc_);                          \
                 if (sc_ > (THR)) continue;                                                             \
             }                                                                                          \
-            if (!(kDiag && (p.ablate & 32u)) && PCNT < p.capl) POOL[PCNT] = make_raw_key(sc_, tr0 + rowb + 8 * (J_) + e_); /* diag 32: count only */ \
+            if (!(kDiag && (p.ablate & 32u)) && PCNT < p.capl) POOL[PCNT] = make_raw_key(sc_, tr0 + rowb_ + 8 * (J_) + e_); /* diag 32: count only */ \
             ++PCNT;                                                                                    \
         }                                                                                              \
     }
-#define VDB_RARE(I_, Q_, THP, THR, NG, POOL, PCNT)                                                     \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                 \
-        VDB_SCORES(I_, j_, Q_, r01_, r23_)                                                             \
-        VDB_APPEND(I_, j_, r01_.x, r01_.y, r23_.x, r23_.y, THP, THR, NG, POOL, PCNT)                   \
+#define VDB_RARE(I_, Q_)                                                                               \
+    {                                                                                                  \
+        uint64_t* const pool_q = p.pool + (size_t)(wq >> 1) * p.pool_block_stride + sub_of(Q_) * p.capl;   /* queries 128 wq .. + 127: block wq >> 1 */ \
+        uint32_t hh_ = h;                      /* tile-row of element (j = 0, e = 0), recomputed here for the same reason */ \
+        asm volatile("" : "+v"(hh_));                                                                  \
+        const uint32_t rowb_ = wr * 64 + (I_) * 32 + 4 * hh_;                                          \
+        uint32_t cnt_ = (pcnt_pk[(Q_) >> 1] >> (16 * ((Q_) & 1))) & 0xffffu;                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                             \
+            VDB_SCORES(I_, j_, Q_, r01_, r23_)                                                         \
+            VDB_APPEND(I_, j_, r01_.x, r01_.y, r23_.x, r23_.y, thp[Q_], thr_q[Q_], ng[Q_], pool_q, cnt_) \
+        }                                                                                              \
+        if (cnt_ > 0xffffu) cnt_ = 0xffffu;                                                            \
+        pcnt_pk[(Q_) >> 1] = (pcnt_pk[(Q_) >> 1] & ~(0xffffu << (16 * ((Q_) & 1)))) | (cnt_ << (16 * ((Q_) & 1))); \
     }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const uint32_t vbits = (uint32_t)(val[i >> 1] >> (32 * (i & 1) + 4 * h));
-                const uint32_t rowb = wr * 128 + i * 32 + 4 * h;       // tile-row of element (j = 0, e = 0)
-                unsigned long long ha = 0ull, hb = 0ull;               // lanes with a possible hit in this row block, per query
+                const uint32_t vbits = (uint32_t)(val >> (32 * i + 4 * h));
+                unsigned long long hit[QT] = {0ull, 0ull, 0ull, 0ull};  // lanes with a possible hit in this row block, per query
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    // scores of 4 rows x 2 queries (two rows per v_pk_fma_f32: the same IEEE fma per element, half the instructions)
+                    // scores of 4 rows x 4 queries (two rows per v_pk_fma_f32: the same IEEE fma per element, half the instructions)
                     const float4 a4 = *reinterpret_cast<const float4*>(al + i * 32 + 8 * j);
                     const float4 b4 = *reinterpret_cast<const float4*>(be + i * 32 + 8 * j);
                     const f32x2 al01 = {a4.x, a4.y}, al23 = {a4.z, a4.w}, be01 = {b4.x, b4.y}, be23 = {b4.z, b4.w};
-                    const f32x2 pa01 = {acc[i][0][4 * j + 0], acc[i][0][4 * j + 1]}, pa23 = {acc[i][0][4 * j + 2], acc[i][0][4 * j + 3]};
-                    const f32x2 pb01 = {acc[i][1][4 * j + 0], acc[i][1][4 * j + 1]}, pb23 = {acc[i][1][4 * j + 2], acc[i][1][4 * j + 3]};
-                    const f32x2 ra01 = __builtin_elementwise_fma(pa01, al01, be01), ra23 = __builtin_elementwise_fma(pa23, al23, be23);
-                    const f32x2 rb01 = __builtin_elementwise_fma(pb01, al01, be01), rb23 = __builtin_elementwise_fma(pb23, al23, be23);
-                    if (kDiag && (p.ablate & 4096u)) {                  // diag 4096: round 1's four compares per query (A/B)
-                        ha |= __builtin_amdgcn_ballot_w64(!(ra01.x > thp_a) || !(ra01.y > thp_a) || !(ra23.x > thp_a) || !(ra23.y > thp_a));
-                        hb |= __builtin_amdgcn_ballot_w64(!(rb01.x > thp_b) || !(rb01.y > thp_b) || !(rb23.x > thp_b) || !(rb23.y > thp_b));
-                    } else {
-                        const f32x2 na_ = __builtin_elementwise_min(ra01, ra23), nb_ = __builtin_elementwise_min(rb01, rb23);
-                        ha |= __builtin_amdgcn_ballot_w64(!(fminf(na_.x, na_.y) > thp_a));
-                        hb |= __builtin_amdgcn_ballot_w64(!(fminf(nb_.x, nb_.y) > thp_b));
+#pragma unroll
+                    for (int jq = 0; jq < QT; ++jq) {
+                        const f32x2 p01 = {acc[i][jq][4 * j + 0], acc[i][jq][4 * j + 1]}, p23 = {acc[i][jq][4 * j + 2], acc[i][jq][4 * j + 3]};
+                        const f32x2 r01 = __builtin_elementwise_fma(p01, al01, be01), r23 = __builtin_elementwise_fma(p23, al23, be23);
+                        const f32x2 n_ = __builtin_elementwise_min(r01, r23);
+                        hit[jq] |= __builtin_amdgcn_ballot_w64(!(fminf(n_.x, n_.y) > thp[jq]));
                     }
                     // two groups in flight at a time: with all four the register allocator spills (the kernel sits at 256 VGPRs,
                     // and a scratch access in here costs a vmcnt(0), i.e. a drain of the DMA ring, per tile)
@@ -470,33 +440,20 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
                     asm volatile("" ::: "memory");                      // computing the sums always and selecting with v_cndmask
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        { VDB_SCORES(i, j, 0, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; ha |= __builtin_amdgcn_ballot_w64(t_ != t_); }
-                        { VDB_SCORES(i, j, 1, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; hb |= __builtin_amdgcn_ballot_w64(t_ != t_); }
+                        { VDB_SCORES(i, j, 0, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; hit[0] |= __builtin_amdgcn_ballot_w64(t_ != t_); }
+                        { VDB_SCORES(i, j, 1, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; hit[1] |= __builtin_amdgcn_ballot_w64(t_ != t_); }
+                        { VDB_SCORES(i, j, 2, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; hit[2] |= __builtin_amdgcn_ballot_w64(t_ != t_); }
+                        { VDB_SCORES(i, j, 3, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; hit[3] |= __builtin_amdgcn_ballot_w64(t_ != t_); }
                     }
                 }
-                if (kDiag && (p.ablate & 64u)) {                        // diag 64: the branch is taken, the append is not executed
-                    if (__builtin_expect(ha != 0ull, 0)) { asm volatile("s_nop 1" ::: "memory"); ++pcnt_a; }
-                    if (__builtin_expect(hb != 0ull, 0)) { asm volatile("s_nop 1" ::: "memory"); ++pcnt_b; }
-                } else {
-                    if (__builtin_expect(ha != 0ull, 0)) VDB_RARE(i, 0, thp_a, thr_a, ng_a, pool_a, pcnt_a)
-                    if (__builtin_expect(hb != 0ull, 0)) {
-                        uint64_t* pool_b = pool_a;
-                        asm volatile("" : "+v"(pool_b));               // (keeps hipcc from hoisting the sum out of the loop into a register)
-                        pool_b += (size_t)128 * p.capl;
-                        VDB_RARE(i, 1, thp_b, thr_b, ng_b, pool_b, pcnt_b)
-                    }
-                }
+                if (__builtin_expect(hit[0] != 0ull, 0)) VDB_RARE(i, 0)
+                if (__builtin_expect(hit[1] != 0ull, 0)) VDB_RARE(i, 1)
+                if (__builtin_expect(hit[2] != 0ull, 0)) VDB_RARE(i, 2)
+                if (__builtin_expect(hit[3] != 0ull, 0)) VDB_RARE(i, 3)
             }
 #undef VDB_RARE
 #undef VDB_APPEND
 #undef VDB_SCORES
-            if (SAMPLE) {
-                // one group minimum per (tile, row half, lane half) and query
-                const uint32_t g = (((tile_first + tile * tile_step) * 2 + wr) * 2 + h);
-                // the key's low word only has to make the keys of one query distinct: the group index
-                p.minkeys[(size_t)q_a * p.minkey_stride + g] = best_a < __uint_as_float(0x7f800000u) ? make_key(best_a, g) : EMPTY_KEY;
-                p.minkeys[(size_t)q_b * p.minkey_stride + g] = best_b < __uint_as_float(0x7f800000u) ? make_key(best_b, g) : EMPTY_KEY;
-            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -523,10 +480,8 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
     if (st < total) { run_stage(st, B2{}, std::false_type{}); ++st; }
     if (st < total) { run_stage(st, B0{}, std::false_type{}); ++st; }
     if (st < total) { run_stage(st, B1{}, std::false_type{}); ++st; }
-    p.pool_cnt[sub_a] = pcnt_a;
-    p.pool_cnt[sub_a + 128] = pcnt_b;                                   // query b = query a + 32: 4 counts per query
-    p.pool_cnt[sub_a + 2] = 0;                                          // sub-pools 2 / 3 of the block's layout: unused by this shape
-    p.pool_cnt[sub_a + 130] = 0;
+#pragma unroll
+    for (int j = 0; j < QT; ++j) p.pool_cnt[(size_t)(wq >> 1) * p.cnt_block_stride + sub_of(j)] = (pcnt_pk[j >> 1] >> (16 * (j & 1))) & 0xffffu;
 #undef VDB_DMA
 #undef VDB_DMA_NT
 #undef VDB_DMA_OFF

@@ -125,6 +125,7 @@ struct vdb_hnsw_index {
     double ml = 0;
     uint64_t rng = 0;
     std::vector<Node> nodes;                                      // indexed by id, like the reference's Vec<Option<HnswNode>>
+    std::vector<uint32_t> row_of_id;                              // device row per id (0xffffffff: absent) -- 4 bytes per node: what the walks' inner loop reads instead of the 80-byte Node
     bool has_ep = false; uint64_t ep = 0; size_t max_level = 0;
     size_t count = 0, dim = 0;
     std::mutex mu;
@@ -154,6 +155,7 @@ struct vdb_hnsw_index {
     bool spec_build = true;                                       // vdb_hnsw_set_build: 0 = the row-scan build of round 2 (A/B, tests)
     uint64_t bstats[8] = {0};                                     // vdb_hnsw_build_stats
     const Node* node(uint64_t id) const { return id < nodes.size() && nodes[id].present ? &nodes[id] : nullptr; }
+    bool has(uint64_t id) const { return id < row_of_id.size() && row_of_id[id] != 0xffffffffu; }
 };
 
 namespace {
@@ -190,7 +192,7 @@ struct LayerSearch {
             if (n && layer < n->nbr.size()) {
                 for (uint64_t nid : n->nbr[layer]) {
                     if (!visited.insert(nid)) continue;
-                    if (!g->node(nid)) continue;                  // skip deleted nodes
+                    if (!g->has(nid)) continue;                   // skip deleted nodes
                     pending.push_back(nid);
                 }
             }
@@ -265,10 +267,12 @@ void mark_dirty(Graph* g, uint64_t id) {
 // order (graph.rs:118-123, level_from_unit / next_unit).
 template <class Fetch> int insert_node(Graph* g, uint64_t id, uint32_t row, size_t level, Fetch&& fetch) {
     if (id >= g->nodes.size()) g->nodes.resize(id + 1);
+    if (id >= g->row_of_id.size()) g->row_of_id.resize(std::max<size_t>(id + 1, g->row_of_id.size() * 2), 0xffffffffu);
     g->graph_version++;
     Node& nd = g->nodes[id];
     nd = Node();
     nd.present = true; nd.level = (uint32_t)level; nd.row = row;
+    g->row_of_id[id] = row;
     nd.nbr.assign(level + 1, {});
     nd.nbr_d.assign(level + 1, {});
     g->count++;
@@ -431,7 +435,7 @@ int add_rows(Graph* g, const uint64_t* ids, uint64_t first_id, const float* rows
             // every distance this insert can ask for: the new vector against the rows stored before it
             const float* scan = g->h_scan[c & 1] + i * g->scan_ld;
             auto fetch = [&](const std::vector<uint64_t>& pend, std::vector<float>& d) -> int {
-                for (size_t t = 0; t < pend.size(); ++t) d[t] = scan[g->nodes[pend[t]].row];
+                for (size_t t = 0; t < pend.size(); ++t) d[t] = scan[g->row_of_id[pend[t]]];
                 return VDB_OK;
             };
             g->bstats[7]++;
@@ -498,6 +502,7 @@ int vdb_hnsw_remove(vdb_hnsw_index* g, uint64_t id) {             // graph.rs:34
     g->mirror_full = true;                                         // lists that still name the node need its row cleared: rebuilt as a whole
     Node gone = std::move(g->nodes[id]);
     g->nodes[id] = Node();
+    if (id < g->row_of_id.size()) g->row_of_id[id] = 0xffffffffu;
     for (size_t l = 0; l < gone.nbr.size(); ++l)
         for (uint64_t nid : gone.nbr[l]) {
             if (nid >= g->nodes.size() || !g->nodes[nid].present || l >= g->nodes[nid].nbr.size()) continue;
@@ -787,7 +792,7 @@ bool walks_supported(const Graph* g) {
 //   the record does not hold is a MISS, evaluated on the GPU at once (one small launch per expansion with misses).
 // The graph is the sequential one by construction -- the replay IS the reference's insert, speculation only decides which
 // distances are already there.  (tests/test_gpu_hnsw.py: node for node equal to the CPU restatement.)
-constexpr uint32_t WALKS = 256, REC_CAP = 8192;
+constexpr uint32_t WALKS = 256, REC_CAP = 12288;          // (the walk's visited set holds 12288 nodes: a longer walk fails anyway)
 
 int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n, const std::vector<uint32_t>& rowv,
                       const std::vector<size_t>& lev, size_t* done) {
@@ -822,8 +827,9 @@ int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n
     size_t up_have = 0;
     for (const Node& nd : g->nodes) if (nd.present) up_have += nd.level;
     if (max_id + 1 > g->cap_ids || up_have + up_need > g->cap_upper) g->mirror_full = true;
-    std::vector<uint32_t> tab_row(16384), fetch_miss_idx, miss_a, miss_b;
-    std::vector<float> tab_d(16384), tri, miss_d;
+    constexpr uint32_t TAB = 32768;                                 // hash slots of an insert's record (at most REC_CAP entries)
+    std::vector<uint32_t> tab_row(TAB), fetch_miss_idx, miss_a, miss_b;
+    std::vector<float> tab_d(TAB), tri, miss_d;
     std::unordered_map<uint32_t, uint32_t> in_chunk;
     std::vector<uint32_t> pa, pb;
     for (size_t c0 = 0; c0 < n; c0 += WALKS) {
@@ -866,28 +872,28 @@ int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n
         for (size_t i = 0; i < nc; ++i) {
             const uint64_t id = ids ? ids[c0 + i] : first_id + c0 + i;
             const uint32_t my_row = rowv[c0 + i];
-            // this insert's record as a hash table row -> distance (16384 slots, at most 8192 entries)
+            // this insert's record as a hash table row -> distance
             std::fill(tab_row.begin(), tab_row.end(), 0xffffffffu);
             const uint32_t cnt = have_graph ? std::min<uint32_t>(g->h_rec_cnt[i], REC_CAP) : 0u;
             const uint32_t* rr = g->h_rec_row + (size_t)i * REC_CAP;
             const float* rd = g->h_rec_d + (size_t)i * REC_CAP;
             for (uint32_t t = 0; t < cnt; ++t) {
-                uint32_t h = (rr[t] * 0x9e3779b1u) >> 18;
-                while (tab_row[h] != 0xffffffffu && tab_row[h] != rr[t]) h = (h + 1) & 16383u;
+                uint32_t h = (rr[t] * 0x9e3779b1u) >> 17;
+                while (tab_row[h] != 0xffffffffu && tab_row[h] != rr[t]) h = (h + 1) & (TAB - 1);
                 tab_row[h] = rr[t]; tab_d[h] = rd[t];
             }
             auto fetch = [&](const std::vector<uint64_t>& pend, std::vector<float>& d) -> int {
                 fetch_miss_idx.clear();
                 for (size_t t = 0; t < pend.size(); ++t) {
-                    const uint32_t row = g->nodes[pend[t]].row;
+                    const uint32_t row = g->row_of_id[pend[t]];
                     auto ic = (row >= row_lo && row <= row_hi) ? in_chunk.find(row) : in_chunk.end();
                     if (ic != in_chunk.end()) {                          // a vector of this chunk, inserted before this one
                         const uint32_t a = (uint32_t)i, b = ic->second;
                         d[t] = a > b ? tri[(size_t)a * (a - 1) / 2 + b] : tri[(size_t)b * (b - 1) / 2 + a];
                         continue;
                     }
-                    uint32_t h = (row * 0x9e3779b1u) >> 18;
-                    while (tab_row[h] != 0xffffffffu && tab_row[h] != row) h = (h + 1) & 16383u;
+                    uint32_t h = (row * 0x9e3779b1u) >> 17;
+                    while (tab_row[h] != 0xffffffffu && tab_row[h] != row) h = (h + 1) & (TAB - 1);
                     if (tab_row[h] == row) d[t] = tab_d[h];
                     else fetch_miss_idx.push_back((uint32_t)t);
                 }
@@ -895,7 +901,7 @@ int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n
                     miss_a.assign(fetch_miss_idx.size(), my_row);
                     miss_b.resize(fetch_miss_idx.size());
                     miss_d.resize(fetch_miss_idx.size());
-                    for (size_t t = 0; t < fetch_miss_idx.size(); ++t) miss_b[t] = g->nodes[pend[fetch_miss_idx[t]]].row;
+                    for (size_t t = 0; t < fetch_miss_idx.size(); ++t) miss_b[t] = g->row_of_id[pend[fetch_miss_idx[t]]];
                     int r2 = vdb_internal::rows_eval(g->flat, miss_a.data(), miss_b.data(), miss_a.size(), miss_d.data());
                     if (r2) return r2;
                     for (size_t t = 0; t < fetch_miss_idx.size(); ++t) d[fetch_miss_idx[t]] = miss_d[t];
