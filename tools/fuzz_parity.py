@@ -7,6 +7,10 @@ and (on a sample of queries) with the CPU oracle.  Any mismatch prints the faili
 
 --shadow additionally runs every case with the opt-in bf16 shadow rows (vdb_flat_set_shadow) and with the sample cache off
 (vdb_flat_set_sample_cache(0)): same results, same tier counters.
+--round3 additionally runs every case (i) with the 512-query filter kernel off (vdb_flat_set_wide(0): batches above 256
+queries), (ii) with the direct path of small indexes off (VDB_TIERS_NO_DIRECT), and (iii) through ONE sharded handle over 2-4
+shards on device 0 (vdb_flat_create_sharded, peer exchange): same results; it also draws small indexes (3 .. 16384 rows),
+batches up to 1100 queries and per-query k.
 """
 import argparse
 import os
@@ -48,6 +52,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-rows", type=int, default=300000)
     ap.add_argument("--shadow", action="store_true")
+    ap.add_argument("--round3", action="store_true")
     a = ap.parse_args()
     vdb = load_package()
     vdb.build()
@@ -57,12 +62,14 @@ def main():
     tiers = {"screen": 0, "rethr": 0, "f32q": 0, "exact": 0, "ovf": 0}
     for case in range(a.cases):
         n = int(rng.integers(16385, a.max_rows))
+        if a.round3 and rng.random() < 0.3:
+            n = int(rng.integers(3, 16385))                           # the dense-scores / direct paths
         d = int(rng.choice([1, 3, 17, 32, 33, 64, 100, 128, 200, 384, 768]))
         if n * d > 120_000_000:
             n = 120_000_000 // d
         metric = int(rng.integers(0, 3))
         kind = str(rng.choice(kinds))
-        nq = int(rng.choice([1, 2, 31, 32, 33, 100, 256, 257, 300]))
+        nq = int(rng.choice([1, 2, 31, 32, 33, 100, 256, 257, 300] + ([7, 8, 9, 511, 512, 513, 700, 1024, 1100] if a.round3 else [])))
         k = int(rng.choice([1, 2, 10, 10, 10, 30, 48, 49, 100, 112, 113, 150]))
         rows = make_data(rng, n, d, kind)
         if metric == 1:
@@ -116,6 +123,30 @@ def main():
             for ax, sx in ((a2, s2), (a3, s3)):
                 ok &= all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(a1, ax))
                 ok &= all(sx[c] == st[c] for c in ctr)
+        if a.round3:
+            same = lambda u, v: all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(u, v))   # noqa: E731
+            ix.set_screen(1)
+            ix.set_wide(False)
+            ok &= same(a1, ix.search_batch_arrays(queries, k, **kw))
+            ix.set_wide(True)
+            ix.set_tiers(ix.TIERS_NO_DIRECT)
+            ok &= same(a1, ix.search_batch_arrays(queries, k, **kw))
+            ix.set_tiers(0)
+            G = int(rng.integers(2, 5))
+            sh = vdb.GpuFlatIndex(vdb.DistanceMetric(metric), devices=[0] * G, keep_host_copy=False)
+            half = n // 2
+            sh.add_bulk(rows[:half], ids=None if ids is None else ids[:half], first_id=0)            # two bulks: the second on top of the first
+            sh.add_bulk(rows[half:], ids=None if ids is None else ids[half:], first_id=half)
+            for r in np.nonzero(live == 0)[0]:
+                sh.remove(int(ids[r]) if ids is not None else int(r))
+            ok &= same(a1, sh.search_batch_arrays(queries, k, **kw))
+            if nq > 1 and mask is None:                                                           # per-query k: a prefix of the batch-wide result
+                ks = rng.integers(0, k + 1, nq).astype(np.uintp)
+                pi, pd, pc = sh.search_batch_arrays(queries, ks)
+                for b in range(0, nq, max(1, nq // 7)):
+                    kb = int(min(ks[b], a1[2][b]))
+                    ok &= bool(pc[b] == kb and np.array_equal(pi[b, :kb], a1[0][b, :kb]) and np.array_equal(pd[b, :kb].view(np.uint32), a1[1][b, :kb].view(np.uint32)))
+            del sh
         for b in sorted({0, nq // 2, nq - 1}):
             oi, od = oracle.flat_search(metric, rows, queries[b], k, ids=ids, live=elig)
             gi, gd, gc = a1
