@@ -398,7 +398,7 @@ struct HnswSearchParams {
     uint32_t* status;
     // INSERT WALKS (vdb_hnsw.cpp build): the "query" is a STORED row (qrow[q], its norm nd[qrow[q]]) that the graph does not hold
     // yet, the walk is insert()'s (graph.rs:262-297): ef = 1 above the node's level qlevel[q], ef at and below it, and every
-    // distance it evaluates is RECORDED -- rec_row / rec_d [q * rec_cap + i], rec_cnt[q] entries (may exceed rec_cap: the rest
+    // distance it evaluates is RECORDED -- rec_row (the evaluated node's ID) / rec_d [q * rec_cap + i], rec_cnt[q] entries (may exceed rec_cap: the rest
     // was dropped) -- for the host's authoritative replay.  All null in a search.  A zero-norm Cosine pair is recorded as
     // rec_zero_mark and ends the walk.
     const uint32_t* qrow; const uint32_t* qlevel;

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(HT) void hnsw_search_kernel(HnswSearchParams p) {
         if (p.rec_row) {                                            // insert walks: every evaluated (row, distance), in order
             const uint32_t base = sRec;
             if (tid < np && base + tid < p.rec_cap) {
-                p.rec_row[(size_t)q * p.rec_cap + base + tid] = sPendRow[tid];
+                p.rec_row[(size_t)q * p.rec_cap + base + tid] = sPendId[tid];      // the NODE ID: the host replay looks distances up by id
                 p.rec_d[(size_t)q * p.rec_cap + base + tid] = sPendD[tid];
             }
             __syncthreads();

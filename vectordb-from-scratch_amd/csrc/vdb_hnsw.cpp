@@ -86,22 +86,31 @@ template <int SIGN> struct RustHeap {
     void clear() { v.clear(); }
 };
 
-// membership-only id set (graph.rs:151 HashSet<usize>): open addressing, grows by doubling
+// membership-only id set (graph.rs:151 HashSet<usize>): open addressing, grows by doubling.  A slot holds (epoch << 32 | id) --
+// node ids are below 2^32 - 16 -- and only slots of the current epoch count as occupied, so clear() is one increment: a walk at
+// 1M nodes visits ~6000 ids on each of up to 6 layers, and refilling (or re-growing) the table per layer showed in the build.
 struct IdSet {
     std::vector<uint64_t> t;
     size_t used = 0;
-    void clear() { t.assign(1024, ~0ull); used = 0; }
+    uint32_t epoch = 0;
+    void clear() {
+        if (t.empty()) t.assign(1024, 0ull);
+        if (++epoch == 0) { std::fill(t.begin(), t.end(), 0ull); epoch = 1; }
+        used = 0;
+    }
     static size_t h(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; return (size_t)x; }
     bool insert(uint64_t id) {                                    // true when newly inserted
         if (t.empty()) clear();
         if (2 * (used + 1) > t.size()) {
             std::vector<uint64_t> old; old.swap(t);
-            t.assign(old.size() * 2, ~0ull); used = 0;
-            for (uint64_t x : old) if (x != ~0ull) insert(x);
+            t.assign(old.size() * 2, 0ull); used = 0;
+            const uint32_t e = epoch;
+            for (uint64_t x : old) if ((uint32_t)(x >> 32) == e) insert(x & 0xffffffffull);
         }
+        const uint64_t key = ((uint64_t)epoch << 32) | (id & 0xffffffffull);
         size_t m = t.size() - 1, i = h(id) & m;
-        while (t[i] != ~0ull) { if (t[i] == id) return false; i = (i + 1) & m; }
-        t[i] = id; ++used;
+        while ((uint32_t)(t[i] >> 32) == epoch) { if (t[i] == key) return false; i = (i + 1) & m; }
+        t[i] = key; ++used;
         return true;
     }
 };
@@ -155,7 +164,8 @@ struct vdb_hnsw_index {
     bool spec_build = true;                                       // vdb_hnsw_set_build: 0 = the row-scan build of round 2 (A/B, tests)
     uint64_t bstats[8] = {0};                                     // vdb_hnsw_build_stats
     const Node* node(uint64_t id) const { return id < nodes.size() && nodes[id].present ? &nodes[id] : nullptr; }
-    bool has(uint64_t id) const { return id < row_of_id.size() && row_of_id[id] != 0xffffffffu; }
+    bool removed_any = false;                                     // no removal so far: every listed neighbour exists, the walks skip the presence check
+    bool has(uint64_t id) const { return !removed_any || (id < row_of_id.size() && row_of_id[id] != 0xffffffffu); }
 };
 
 namespace {
@@ -503,6 +513,7 @@ int vdb_hnsw_remove(vdb_hnsw_index* g, uint64_t id) {             // graph.rs:34
     Node gone = std::move(g->nodes[id]);
     g->nodes[id] = Node();
     if (id < g->row_of_id.size()) g->row_of_id[id] = 0xffffffffu;
+    g->removed_any = true;
     for (size_t l = 0; l < gone.nbr.size(); ++l)
         for (uint64_t nid : gone.nbr[l]) {
             if (nid >= g->nodes.size() || !g->nodes[nid].present || l >= g->nodes[nid].nbr.size()) continue;
@@ -830,7 +841,7 @@ int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n
     constexpr uint32_t TAB = 32768;                                 // hash slots of an insert's record (at most REC_CAP entries)
     std::vector<uint32_t> tab_row(TAB), fetch_miss_idx, miss_a, miss_b;
     std::vector<float> tab_d(TAB), tri, miss_d;
-    std::unordered_map<uint32_t, uint32_t> in_chunk;
+    std::unordered_map<uint64_t, uint32_t> in_chunk;                // node id -> position in the chunk
     std::vector<uint32_t> pa, pb;
     for (size_t c0 = 0; c0 < n; c0 += WALKS) {
         const size_t nc = std::min<size_t>(WALKS, n - c0);
@@ -853,8 +864,11 @@ int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n
         }
         // ---- distances between the chunk's own vectors: pair (i, j), j < i, at tri[i (i - 1) / 2 + j]
         in_chunk.clear();
-        uint32_t row_lo = 0xffffffffu, row_hi = 0;
-        for (size_t i = 0; i < nc; ++i) { in_chunk[rowv[c0 + i]] = (uint32_t)i; row_lo = std::min(row_lo, rowv[c0 + i]); row_hi = std::max(row_hi, rowv[c0 + i]); }
+        uint64_t id_lo = ~0ull, id_hi = 0;
+        for (size_t i = 0; i < nc; ++i) {
+            const uint64_t cid = ids ? ids[c0 + i] : first_id + c0 + i;
+            in_chunk[cid] = (uint32_t)i; id_lo = std::min(id_lo, cid); id_hi = std::max(id_hi, cid);
+        }
         pa.clear(); pb.clear();
         for (size_t i = 1; i < nc; ++i) for (size_t j = 0; j < i; ++j) { pa.push_back(rowv[c0 + i]); pb.push_back(rowv[c0 + j]); }
         tri.resize(pa.size());
@@ -872,7 +886,8 @@ int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n
         for (size_t i = 0; i < nc; ++i) {
             const uint64_t id = ids ? ids[c0 + i] : first_id + c0 + i;
             const uint32_t my_row = rowv[c0 + i];
-            // this insert's record as a hash table row -> distance
+            // this insert's record as a hash table node id -> distance (ids, not rows: the replay's inner loop then touches nothing but
+            // this table -- a per-distance lookup in the 4 MB id -> row array was a third of its time at 1M nodes)
             std::fill(tab_row.begin(), tab_row.end(), 0xffffffffu);
             const uint32_t cnt = have_graph ? std::min<uint32_t>(g->h_rec_cnt[i], REC_CAP) : 0u;
             const uint32_t* rr = g->h_rec_row + (size_t)i * REC_CAP;
@@ -885,8 +900,9 @@ int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n
             auto fetch = [&](const std::vector<uint64_t>& pend, std::vector<float>& d) -> int {
                 fetch_miss_idx.clear();
                 for (size_t t = 0; t < pend.size(); ++t) {
-                    const uint32_t row = g->row_of_id[pend[t]];
-                    auto ic = (row >= row_lo && row <= row_hi) ? in_chunk.find(row) : in_chunk.end();
+                    const uint64_t nid = pend[t];
+                    const uint32_t row = (uint32_t)nid;                    // (table key: node ids are below 2^32 - 16)
+                    auto ic = (nid >= id_lo && nid <= id_hi) ? in_chunk.find(nid) : in_chunk.end();
                     if (ic != in_chunk.end()) {                          // a vector of this chunk, inserted before this one
                         const uint32_t a = (uint32_t)i, b = ic->second;
                         d[t] = a > b ? tri[(size_t)a * (a - 1) / 2 + b] : tri[(size_t)b * (b - 1) / 2 + a];
