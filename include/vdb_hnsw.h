@@ -14,9 +14,12 @@
  * the host with the candidate lists of ALL in-flight queries evaluated in one launch per traversal round.  Both give
  * the reference's results; there is no CPU distance path.
  *
- * Inserts are sequential by definition and make no GPU round trip each: the distances are produced ahead of the walks
- * (16 new vectors per pass over the stored rows, the next chunk scanned while the host walks the current one) and every
- * edge keeps the distance it was created with, so a prune (graph.rs:207-241) recomputes nothing.
+ * Inserts are sequential by definition and make no GPU round trip per neighbour expansion.  Bulk inserts evaluate FRONTIERS
+ * ONLY: per chunk of 256 inserts one launch of the device-resident walk (insert mode) evaluates what every insert's
+ * search_layer asks for on the graph as of the chunk's start and records it; the host then replays the inserts in order with
+ * the reference's algorithm, reading distances from the records and asking the GPU again only where the real walk left the
+ * speculative one (vdb_hnsw_set_build, vdb_hnsw_build_stats).  Single adds and small batches scan the stored rows ahead of
+ * the walk instead.  Every edge keeps the distance it was created with, so a prune (graph.rs:207-241) recomputes nothing.
  *
  * Not reproducible in the reference and fixed here: node levels come from StdRng::from_entropy() (graph.rs:101);
  * this index draws them from a seeded splitmix64 stream (`seed`), with the reference's formula (graph.rs:118-123).
