@@ -90,6 +90,10 @@ int vdb_hnsw_set_build(vdb_hnsw_index *h, int frontier_only);
  * [4] such round trips, [5] walks whose record overflowed, [6] distances the host's inserts consumed (what the reference's
  * algorithm evaluates), [7] inserts of the row-scan build. */
 int vdb_hnsw_build_stats(const vdb_hnsw_index *h, uint64_t out[8]);
+/* Where the frontier-only builds spent their wall time, seconds since creation: [0] bringing the device mirror of the graph up to
+ * date (once per chunk), [1] waiting for the chunk's device walks and its in-chunk distances, [2] the host's replay of the inserts
+ * (the reference's algorithm, distances read from the records), of which [3] were round trips for missed distances. */
+int vdb_hnsw_build_times(const vdb_hnsw_index *h, double out[4]);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,7 @@ def main():
     g = vdb.GpuHnswIndex(vdb.DistanceMetric(a.metric), vdb.HnswParams.new(a.m, a.efc, 50), seed=1)
     if a.scan_build:
         g.set_build(False)
+
     t0 = time.perf_counter()
     step = 20000
     for c0 in range(0, a.rows, step):
@@ -49,6 +50,7 @@ def main():
     print(f"build: {a.rows} x {a.dim}, m={a.m} ef_construction={a.efc}: {t_build:.1f} s "
           f"({1e3 * t_build / a.rows:.3f} ms per insert), GPU distances {st['gpu_distances']:.3e}, launches {st['gpu_launches']}", flush=True)
     print("build stats:", g.build_stats(), flush=True)
+    print("build times:", g.build_times(), flush=True)
     g.search_batch_arrays(queries, a.k, a.ef)
     t0 = time.perf_counter()
     reps = 3

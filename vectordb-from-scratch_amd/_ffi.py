@@ -20,7 +20,7 @@ SYMBOLS = [
     # include/vdb_hnsw.h
     "vdb_hnsw_create", "vdb_hnsw_destroy", "vdb_hnsw_add", "vdb_hnsw_add_bulk", "vdb_hnsw_remove", "vdb_hnsw_search_batch",
     "vdb_hnsw_len", "vdb_hnsw_metric", "vdb_hnsw_get_vector", "vdb_hnsw_neighbors", "vdb_hnsw_node_level",
-    "vdb_hnsw_entry_point", "vdb_hnsw_stats", "vdb_hnsw_set_traversal", "vdb_hnsw_set_build", "vdb_hnsw_build_stats",
+    "vdb_hnsw_entry_point", "vdb_hnsw_stats", "vdb_hnsw_set_traversal", "vdb_hnsw_set_build", "vdb_hnsw_build_stats", "vdb_hnsw_build_times",
     # include/vdb_shard.h
     "vdb_shard_unique_id", "vdb_shard_group_create", "vdb_shard_group_destroy", "vdb_shard_group_rank", "vdb_shard_group_world",
     "vdb_shard_range", "vdb_flat_search_batch_sharded", "vdb_shard_group_last_stats",
@@ -135,6 +135,7 @@ def lib():
     L.vdb_hnsw_set_traversal.argtypes = [vp, c.c_int, sz]
     L.vdb_hnsw_set_build.argtypes = [vp, c.c_int]
     L.vdb_hnsw_build_stats.argtypes = [vp, u64p]
+    L.vdb_hnsw_build_times.argtypes = [vp, c.POINTER(c.c_double)]
     L.vdb_shard_unique_id.argtypes = [c.c_char_p]
     L.vdb_shard_group_create.argtypes = [c.c_char_p, c.c_int, c.c_int, c.c_int, c.POINTER(vp)]
     L.vdb_shard_group_destroy.argtypes = [vp]

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -163,6 +164,7 @@ struct vdb_hnsw_index {
     float *h_rec_d = nullptr, *d_rec_d = nullptr;
     bool spec_build = true;                                       // vdb_hnsw_set_build: 0 = the row-scan build of round 2 (A/B, tests)
     uint64_t bstats[8] = {0};                                     // vdb_hnsw_build_stats
+    double btimes[4] = {0, 0, 0, 0};                              // vdb_hnsw_build_times
     const Node* node(uint64_t id) const { return id < nodes.size() && nodes[id].present ? &nodes[id] : nullptr; }
     bool removed_any = false;                                     // no removal so far: every listed neighbour exists, the walks skip the presence check
     bool has(uint64_t id) const { return !removed_any || (id < row_of_id.size() && row_of_id[id] != 0xffffffffu); }
@@ -190,6 +192,19 @@ struct LayerSearch {
         pending.assign(1, ep);
         stage = 0; zero_norm = false;
     }
+    // The walk is a chain of dependent cache misses at a million nodes (node -> its list table -> the layer's list): the node
+    // most likely to be expanded NEXT -- the top of the candidate heap -- is pulled towards the cache one level per call, while
+    // the current expansion's distances are fetched and folded.
+    void prefetch_next(int depth) const {
+        if (cand.empty()) return;
+        const uint64_t id = cand.top().id;
+        if (id >= g->nodes.size()) return;
+        const Node& n = g->nodes[id];
+        if (depth == 0) { __builtin_prefetch(&n); return; }
+        if (!n.present || layer >= n.nbr.size()) return;
+        if (depth == 1) { __builtin_prefetch(&n.nbr[layer]); return; }
+        __builtin_prefetch(n.nbr[layer].data());
+    }
     bool next_request() {
         if (stage == 0) { stage = 1; return true; }
         while (true) {
@@ -200,13 +215,14 @@ struct LayerSearch {
             pending.clear();
             const Node* n = g->node(c.id);
             if (n && layer < n->nbr.size()) {
+                prefetch_next(1);
                 for (uint64_t nid : n->nbr[layer]) {
                     if (!visited.insert(nid)) continue;
                     if (!g->has(nid)) continue;                   // skip deleted nodes
                     pending.push_back(nid);
                 }
             }
-            if (!pending.empty()) return true;
+            if (!pending.empty()) { prefetch_next(2); return true; }
         }
     }
     void feed(const float* d) {
@@ -220,6 +236,7 @@ struct LayerSearch {
             } else {
                 const float furthest = res.empty() ? F32_MAX : res.top().d;
                 if (n.d < furthest || res.size() < ef) {
+                    if (n.id < g->nodes.size()) __builtin_prefetch(&g->nodes[n.id]);
                     cand.push(n);
                     res.push(n);
                     if (res.size() > ef) { Nb drop; res.pop(drop); }
@@ -227,6 +244,7 @@ struct LayerSearch {
             }
         }
         stage = 2;
+        prefetch_next(1);
     }
     std::vector<Nb> sorted() const {                              // into_sorted_vec: backing array, stable sort by distance
         std::vector<Nb> v = res.v;
@@ -290,13 +308,15 @@ template <class Fetch> int insert_node(Graph* g, uint64_t id, uint32_t row, size
     if (!g->has_ep) { g->has_ep = true; g->ep = id; g->max_level = level; return VDB_OK; }
     uint64_t ep_id = g->ep;
     const size_t cur_max = g->max_level;
-    LayerSearch ls;
-    std::vector<float> d;
+    // the walk's state outlives the insert (inserts run under the graph's mutex; per thread, so two indexes do not share it): a
+    // fresh one grew its visited set from 1024 slots to 16384 again -- four re-hashes -- for every insert of a large build
+    static thread_local LayerSearch ls;
+    static thread_local std::vector<float> d;
     auto run_layer = [&](size_t ef, size_t layer, std::vector<Nb>& out) -> int {
         ls.start(g, ep_id, ef, layer);
         while (ls.next_request()) {
             d.resize(ls.pending.size());
-            int frc = fetch(ls.pending, d);
+            int frc = fetch(ls.pending, d, layer);
             if (frc) return frc;
             g->bstats[6] += d.size();
             ls.feed(d.data());
@@ -306,14 +326,13 @@ template <class Fetch> int insert_node(Graph* g, uint64_t id, uint32_t row, size
         return VDB_OK;
     };
     int rc;
-    std::vector<Nb> nearest;
+    static thread_local std::vector<Nb> nearest, scored;
     if (cur_max > level)
         for (size_t l = cur_max; l >= level + 1; --l) {
             if ((rc = run_layer(1, l, nearest))) return rc;
             if (!nearest.empty()) ep_id = nearest[0].id;
         }
     const size_t from = std::min(level, cur_max);
-    std::vector<Nb> scored;
     for (size_t l = from;; --l) {
         const size_t m = l == 0 ? g->m_max0 : g->m;
         if ((rc = run_layer(g->ef_construction, l, nearest))) return rc;
@@ -325,6 +344,17 @@ template <class Fetch> int insert_node(Graph* g, uint64_t id, uint32_t row, size
         }
         // bidirectional links (graph.rs:303-327); a list that grew beyond m is pruned at once (prune_neighbors, :207-241):
         // its entries scored by their distance to the list's owner -- the cached edge distances --, stable sort, truncate
+        // (the `take` owners are scattered over the node array: three rounds of independent prefetches instead of 3 x take
+        // dependent misses)
+        for (size_t i = 0; i < take; ++i) __builtin_prefetch(&g->nodes[nearest[i].id]);
+        for (size_t i = 0; i < take; ++i) {
+            const Node& nb = g->nodes[nearest[i].id];
+            if (nb.present && l < nb.nbr.size()) { __builtin_prefetch(&nb.nbr[l]); __builtin_prefetch(&nb.nbr_d[l]); }
+        }
+        for (size_t i = 0; i < take; ++i) {
+            const Node& nb = g->nodes[nearest[i].id];
+            if (nb.present && l < nb.nbr.size()) { __builtin_prefetch(nb.nbr[l].data()); __builtin_prefetch(nb.nbr_d[l].data()); }
+        }
         for (size_t i = 0; i < take; ++i) {
             Node& nb = g->nodes[nearest[i].id];
             if (!nb.present || l >= nb.nbr.size()) continue;
@@ -444,7 +474,7 @@ int add_rows(Graph* g, const uint64_t* ids, uint64_t first_id, const float* rows
             const uint64_t id = ids ? ids[c0 + i] : first_id + c0 + i;
             // every distance this insert can ask for: the new vector against the rows stored before it
             const float* scan = g->h_scan[c & 1] + i * g->scan_ld;
-            auto fetch = [&](const std::vector<uint64_t>& pend, std::vector<float>& d) -> int {
+            auto fetch = [&](const std::vector<uint64_t>& pend, std::vector<float>& d, size_t) -> int {
                 for (size_t t = 0; t < pend.size(); ++t) d[t] = scan[g->row_of_id[pend[t]]];
                 return VDB_OK;
             };
@@ -846,7 +876,9 @@ int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n
     for (size_t c0 = 0; c0 < n; c0 += WALKS) {
         const size_t nc = std::min<size_t>(WALKS, n - c0);
         // ---- the mirror as of the chunk's start; the walks of the chunk on it
+        const auto t_chunk = std::chrono::steady_clock::now();
         if ((rc = sync_mirror(g, s, max_id + 1, up_have + up_need))) return rc;
+        const auto t_synced = std::chrono::steady_clock::now();
         const bool have_graph = g->has_ep;
         if (have_graph) {
             for (size_t i = 0; i < nc; ++i) { g->h_wq[i] = rowv[c0 + i]; g->h_wq[WALKS + i] = (uint32_t)lev[c0 + i]; }
@@ -869,6 +901,8 @@ int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n
             const uint64_t cid = ids ? ids[c0 + i] : first_id + c0 + i;
             in_chunk[cid] = (uint32_t)i; id_lo = std::min(id_lo, cid); id_hi = std::max(id_hi, cid);
         }
+        bool dense_ids = id_hi - id_lo + 1 == nc;                     // ids lo .. lo + nc - 1 in order: position = id - lo
+        for (size_t i = 0; i < nc && dense_ids; ++i) dense_ids = (ids ? ids[c0 + i] : first_id + c0 + i) == id_lo + i;
         pa.clear(); pb.clear();
         for (size_t i = 1; i < nc; ++i) for (size_t j = 0; j < i; ++j) { pa.push_back(rowv[c0 + i]); pb.push_back(rowv[c0 + j]); }
         tri.resize(pa.size());
@@ -883,6 +917,13 @@ int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n
                 if (g->h_rec_cnt[i] > REC_CAP) g->bstats[5]++;
             }
         // ---- the authoritative replay, insert by insert
+        const auto t_walked = std::chrono::steady_clock::now();
+        g->btimes[0] += std::chrono::duration<double>(t_synced - t_chunk).count();
+        g->btimes[1] += std::chrono::duration<double>(t_walked - t_synced).count();
+        struct ReplayClock {
+            Graph* g; std::chrono::steady_clock::time_point t0;
+            ~ReplayClock() { g->btimes[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+        } replay_clock{g, t_walked};
         for (size_t i = 0; i < nc; ++i) {
             const uint64_t id = ids ? ids[c0 + i] : first_id + c0 + i;
             const uint32_t my_row = rowv[c0 + i];
@@ -897,28 +938,37 @@ int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n
                 while (tab_row[h] != 0xffffffffu && tab_row[h] != rr[t]) h = (h + 1) & (TAB - 1);
                 tab_row[h] = rr[t]; tab_d[h] = rd[t];
             }
-            auto fetch = [&](const std::vector<uint64_t>& pend, std::vector<float>& d) -> int {
+            auto fetch = [&](const std::vector<uint64_t>& pend, std::vector<float>& d, size_t) -> int {
                 fetch_miss_idx.clear();
                 for (size_t t = 0; t < pend.size(); ++t) {
                     const uint64_t nid = pend[t];
-                    const uint32_t row = (uint32_t)nid;                    // (table key: node ids are below 2^32 - 16)
-                    auto ic = (nid >= id_lo && nid <= id_hi) ? in_chunk.find(nid) : in_chunk.end();
-                    if (ic != in_chunk.end()) {                          // a vector of this chunk, inserted before this one
-                        const uint32_t a = (uint32_t)i, b = ic->second;
-                        d[t] = a > b ? tri[(size_t)a * (a - 1) / 2 + b] : tri[(size_t)b * (b - 1) / 2 + a];
-                        continue;
+                    if (nid >= id_lo && nid <= id_hi) {                  // a vector of this chunk, inserted before this one?
+                        long cp = -1;
+                        if (dense_ids) cp = (long)(nid - id_lo);
+                        else { auto ic = in_chunk.find(nid); if (ic != in_chunk.end()) cp = (long)ic->second; }
+                        if (cp >= 0) {
+                            const uint32_t a = (uint32_t)i, b = (uint32_t)cp;
+                            d[t] = a > b ? tri[(size_t)a * (a - 1) / 2 + b] : tri[(size_t)b * (b - 1) / 2 + a];
+                            continue;
+                        }
                     }
-                    uint32_t h = (row * 0x9e3779b1u) >> 17;
-                    while (tab_row[h] != 0xffffffffu && tab_row[h] != row) h = (h + 1) & (TAB - 1);
-                    if (tab_row[h] == row) d[t] = tab_d[h];
+                    const uint32_t key = (uint32_t)nid;                  // (table key: node ids are below 2^32 - 16)
+                    uint32_t h = (key * 0x9e3779b1u) >> 17;
+                    while (tab_row[h] != 0xffffffffu && tab_row[h] != key) h = (h + 1) & (TAB - 1);
+                    if (tab_row[h] == key) d[t] = tab_d[h];
                     else fetch_miss_idx.push_back((uint32_t)t);
                 }
-                if (!fetch_miss_idx.empty()) {                          // the real walk left the speculative one: evaluate now
+                // the real walk left the speculative one: evaluate what it asks for now.  (Tried: the neighbours of the missed nodes
+                // in the same round trip -- 24 % fewer round trips at 200k x 768, but 9x the pairs and the host's bookkeeping for them:
+                // 52.6 s against 47.8 s for the build.)
+                if (!fetch_miss_idx.empty()) {
                     miss_a.assign(fetch_miss_idx.size(), my_row);
                     miss_b.resize(fetch_miss_idx.size());
                     miss_d.resize(fetch_miss_idx.size());
                     for (size_t t = 0; t < fetch_miss_idx.size(); ++t) miss_b[t] = g->row_of_id[pend[fetch_miss_idx[t]]];
+                    const auto t_miss = std::chrono::steady_clock::now();
                     int r2 = vdb_internal::rows_eval(g->flat, miss_a.data(), miss_b.data(), miss_a.size(), miss_d.data());
+                    g->btimes[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_miss).count();
                     if (r2) return r2;
                     for (size_t t = 0; t < fetch_miss_idx.size(); ++t) d[fetch_miss_idx[t]] = miss_d[t];
                     g->stats[0] += miss_a.size(); g->stats[1]++;
@@ -1079,6 +1129,13 @@ int vdb_hnsw_build_stats(const vdb_hnsw_index* g, uint64_t out[8]) {
     return guarded([&]() -> int {
     if (!g || !out) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null argument");
     memcpy(out, g->bstats, sizeof(g->bstats));
+    return VDB_OK;
+    });
+}
+int vdb_hnsw_build_times(const vdb_hnsw_index* g, double out[4]) {
+    return guarded([&]() -> int {
+    if (!g || !out) return vdb_internal::set_error(VDB_ERR_INVALID_ARGUMENT, "null argument");
+    memcpy(out, g->btimes, sizeof(g->btimes));
     return VDB_OK;
     });
 }

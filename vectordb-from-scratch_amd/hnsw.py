@@ -164,3 +164,9 @@ class GpuHnswIndex(Index):
         self._L.vdb_hnsw_build_stats(self._h, out)
         return dict(zip(["frontier_inserts", "walk_distances", "in_chunk_distances", "miss_distances", "miss_round_trips",
                          "record_overflows", "reference_distances", "scan_inserts"], [int(v) for v in out]))
+
+    def build_times(self):
+        """Seconds the frontier-only builds spent: mirror sync, waiting for the device walks, host replay, of which misses."""
+        out = (ctypes.c_double * 4)()
+        self._L.vdb_hnsw_build_times(self._h, out)
+        return dict(zip(["mirror_sync_s", "walks_s", "replay_s", "replay_miss_round_trips_s"], [round(float(v), 3) for v in out]))
