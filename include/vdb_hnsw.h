@@ -15,10 +15,10 @@
  * the reference's results; there is no CPU distance path.
  *
  * Inserts are sequential by definition and make no GPU round trip per neighbour expansion.  Bulk inserts evaluate FRONTIERS
- * ONLY: per chunk of 256 inserts one launch of the device-resident walk (insert mode) evaluates what every insert's
- * search_layer asks for on the graph as of the chunk's start and records it; the host then replays the inserts in order with
- * the reference's algorithm, reading distances from the records and asking the GPU again only where the real walk left the
- * speculative one (vdb_hnsw_set_build, vdb_hnsw_build_stats).  Single adds and small batches scan the stored rows ahead of
+ * ONLY: per block of 128 inserts one launch of the device-resident walk (insert mode) evaluates what every insert's
+ * search_layer asks for and records it -- one block AHEAD of the host, on the graph as of the end of the block before the one
+ * being replayed; the host replays the inserts in order with the reference's algorithm, reading distances from the records and
+ * asking the GPU again only where the real walk left the speculative one (vdb_hnsw_set_build, vdb_hnsw_build_stats).  Single adds and small batches scan the stored rows ahead of
  * the walk instead.  Every edge keeps the distance it was created with, so a prune (graph.rs:207-241) recomputes nothing.
  *
  * Not reproducible in the reference and fixed here: node levels come from StdRng::from_entropy() (graph.rs:101);
@@ -81,17 +81,17 @@ int vdb_hnsw_entry_point(const vdb_hnsw_index *h, uint64_t *id, size_t *max_leve
 int vdb_hnsw_stats(const vdb_hnsw_index *h, uint64_t out[6]);
 
 /* How bulk inserts (vdb_hnsw_add_bulk, 32 vectors or more) get their distances.  1 (default): FRONTIER ONLY -- a device walk per
- * insert evaluates what search_layer asks for (graph.rs:155, :182) on the graph as of the start of its chunk of 256 inserts, the
- * host replays the inserts in order with the reference's algorithm and asks the GPU again only where the real walk left the
- * speculative one.  0: the row-scan build (every stored row against every new vector, N^2 / 2 distances).  Same graph either way. */
+ * insert evaluates what search_layer asks for (graph.rs:155, :182) on the graph as it was 128 + (its position in its block of
+ * 128) inserts earlier, while the host replays the block before; the host replays the inserts in order with the reference's
+ * algorithm and asks the GPU again only where the real walk left the speculative one.  0: the row-scan build (every stored row against every new vector, N^2 / 2 distances).  Same graph either way. */
 int vdb_hnsw_set_build(vdb_hnsw_index *h, int frontier_only);
 /* Counters of the builds since creation: [0] inserts of the frontier-only build, [1] distances its device walks evaluated,
- * [2] distances between vectors of one chunk, [3] distances evaluated after a miss (the real walk left the speculative one),
+ * [2] distances between vectors of one block and of the block before it, [3] distances evaluated after a miss (the real walk left the speculative one),
  * [4] such round trips, [5] walks whose record overflowed, [6] distances the host's inserts consumed (what the reference's
  * algorithm evaluates), [7] inserts of the row-scan build. */
 int vdb_hnsw_build_stats(const vdb_hnsw_index *h, uint64_t out[8]);
 /* Where the frontier-only builds spent their wall time, seconds since creation: [0] bringing the device mirror of the graph up to
- * date (once per chunk), [1] waiting for the chunk's device walks and its in-chunk distances, [2] the host's replay of the inserts
+ * date (once per block), [1] waiting for the block's device walks (they run a block ahead) and its window distances, [2] the host's replay of the inserts
  * (the reference's algorithm, distances read from the records), of which [3] were round trips for missed distances. */
 int vdb_hnsw_build_times(const vdb_hnsw_index *h, double out[4]);
 

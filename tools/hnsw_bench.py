@@ -40,6 +40,7 @@ def main():
     if a.scan_build:
         g.set_build(False)
 
+
     t0 = time.perf_counter()
     step = 20000
     for c0 in range(0, a.rows, step):

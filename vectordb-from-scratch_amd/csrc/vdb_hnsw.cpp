@@ -833,7 +833,12 @@ bool walks_supported(const Graph* g) {
 //   the record does not hold is a MISS, evaluated on the GPU at once (one small launch per expansion with misses).
 // The graph is the sequential one by construction -- the replay IS the reference's insert, speculation only decides which
 // distances are already there.  (tests/test_gpu_hnsw.py: node for node equal to the CPU restatement.)
-constexpr uint32_t WALKS = 256, REC_CAP = 12288;          // (the walk's visited set holds 12288 nodes: a longer walk fails anyway)
+constexpr uint32_t WALKS = 128, REC_CAP = 12288;          // (the walk's visited set holds 12288 nodes: a longer walk fails anyway)
+// The walks run ONE BLOCK AHEAD of the replay, on their own stream: while the host replays block b (128 inserts, ~25 ms), the GPU
+// walks block b + 1 on the graph as of the end of block b - 1 (~12 ms: a walk is a latency chain, 128 of them occupy 128 CUs and
+// leave the rest to the replay's misses).  The host never waits for a walk launch; the price is that an insert's record is
+// 128 + its position inserts stale instead of its position, i.e. more misses -- distances to the vectors of the block in between
+// come from the window matrix below, like those of the insert's own block.
 
 int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n, const std::vector<uint32_t>& rowv,
                       const std::vector<size_t>& lev, size_t* done) {
@@ -842,16 +847,22 @@ int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n
     vdb_internal::DeviceView dv;
     if ((rc = vdb_internal::device_view(g->flat, &dv))) return rc;
     hipStream_t s = (hipStream_t)dv.stream;
-    if (!g->h_wq) {
-        HN_TRY(hipHostMalloc((void**)&g->h_wq, 2 * WALKS * 4, hipHostMallocMapped));
+    if (!g->h_wq) {                                              // two sets of everything a walk launch touches: block b + 1 is walked while b is replayed
+        HN_TRY(hipHostMalloc((void**)&g->h_wq, 2 * 2 * WALKS * 4, hipHostMallocMapped));
         HN_TRY(hipHostGetDevicePointer((void**)&g->d_wq, g->h_wq, 0));
-        HN_TRY(hipHostMalloc((void**)&g->h_rec_cnt, WALKS * 4, hipHostMallocMapped));
+        HN_TRY(hipHostMalloc((void**)&g->h_rec_cnt, 2 * WALKS * 4, hipHostMallocMapped));
         HN_TRY(hipHostGetDevicePointer((void**)&g->d_rec_cnt, g->h_rec_cnt, 0));
-        HN_TRY(hipHostMalloc((void**)&g->h_rec_row, (size_t)WALKS * REC_CAP * 4, hipHostMallocMapped));
+        HN_TRY(hipHostMalloc((void**)&g->h_rec_row, (size_t)2 * WALKS * REC_CAP * 4, hipHostMallocMapped));
         HN_TRY(hipHostGetDevicePointer((void**)&g->d_rec_row, g->h_rec_row, 0));
-        HN_TRY(hipHostMalloc((void**)&g->h_rec_d, (size_t)WALKS * REC_CAP * 4, hipHostMallocMapped));
+        HN_TRY(hipHostMalloc((void**)&g->h_rec_d, (size_t)2 * WALKS * REC_CAP * 4, hipHostMallocMapped));
         HN_TRY(hipHostGetDevicePointer((void**)&g->d_rec_d, g->h_rec_d, 0));
     }
+    if (!g->scan_stream) {
+        HN_TRY(hipStreamCreateWithFlags(&g->scan_stream, hipStreamNonBlocking));
+        HN_TRY(hipEventCreateWithFlags(&g->scan_ev[0], hipEventDisableTiming));
+        HN_TRY(hipEventCreateWithFlags(&g->scan_ev[1], hipEventDisableTiming));
+    }
+    const hipStream_t sw = g->scan_stream;
     if (!g->d_fail || g->out_nq_cap < WALKS) {
         if (g->d_fail) (void)hipFree(g->d_fail);
         if (g->d_out_counts) (void)hipFree(g->d_out_counts);
@@ -870,69 +881,113 @@ int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n
     if (max_id + 1 > g->cap_ids || up_have + up_need > g->cap_upper) g->mirror_full = true;
     constexpr uint32_t TAB = 32768;                                 // hash slots of an insert's record (at most REC_CAP entries)
     std::vector<uint32_t> tab_row(TAB), fetch_miss_idx, miss_a, miss_b;
-    std::vector<float> tab_d(TAB), tri, miss_d;
-    std::unordered_map<uint64_t, uint32_t> in_chunk;                // node id -> position in the chunk
+    std::vector<float> tab_d(TAB), win, miss_d;
     std::vector<uint32_t> pa, pb;
-    for (size_t c0 = 0; c0 < n; c0 += WALKS) {
-        const size_t nc = std::min<size_t>(WALKS, n - c0);
-        // ---- the mirror as of the chunk's start; the walks of the chunk on it
-        const auto t_chunk = std::chrono::steady_clock::now();
-        if ((rc = sync_mirror(g, s, max_id + 1, up_have + up_need))) return rc;
-        const auto t_synced = std::chrono::steady_clock::now();
-        const bool have_graph = g->has_ep;
-        if (have_graph) {
-            for (size_t i = 0; i < nc; ++i) { g->h_wq[i] = rowv[c0 + i]; g->h_wq[WALKS + i] = (uint32_t)lev[c0 + i]; }
+    auto id_of = [&](size_t i) { return ids ? ids[i] : first_id + i; };
+    // a block's ids -> positions: a subtraction when they are consecutive (the usual case), a map otherwise
+    struct BlockIds {
+        uint64_t lo = ~0ull, hi = 0; bool dense = false; size_t nc = 0;
+        std::unordered_map<uint64_t, uint32_t> pos;
+        long find(uint64_t id) const {
+            if (nc == 0 || id < lo || id > hi) return -1;
+            if (dense) return (long)(id - lo);
+            auto it = pos.find(id);
+            return it == pos.end() ? -1 : (long)it->second;
+        }
+    } blk[2];
+    auto describe = [&](BlockIds& B, size_t c0, size_t nc) {
+        B.lo = ~0ull; B.hi = 0; B.nc = nc; B.pos.clear();
+        for (size_t i = 0; i < nc; ++i) { B.lo = std::min<uint64_t>(B.lo, id_of(c0 + i)); B.hi = std::max<uint64_t>(B.hi, id_of(c0 + i)); }
+        B.dense = nc && B.hi - B.lo + 1 == nc;
+        for (size_t i = 0; i < nc && B.dense; ++i) B.dense = id_of(c0 + i) == B.lo + i;
+        if (!B.dense) for (size_t i = 0; i < nc; ++i) B.pos[id_of(c0 + i)] = (uint32_t)i;
+    };
+    // no walk may be in flight when this function returns: it writes the mapped records and reads the mirror
+    struct Drain { hipStream_t st; ~Drain() { (void)hipStreamSynchronize(st); } } drain{sw};
+    bool walked[2] = {false, false};                               // did the block of this parity get a walk launch (a graph existed)?
+    auto launch_walks = [&](size_t b) -> int {                     // the mirror is up to date and no walk is in flight
+        const size_t c0 = b * WALKS, nc = std::min<size_t>(WALKS, n - c0);
+        const uint32_t par = (uint32_t)(b & 1);
+        walked[par] = g->has_ep;
+        if (walked[par]) {
+            uint32_t* wq = g->h_wq + (size_t)par * 2 * WALKS;
+            for (size_t i = 0; i < nc; ++i) { wq[i] = rowv[c0 + i]; wq[WALKS + i] = (uint32_t)lev[c0 + i]; }
             vdb::HnswSearchParams hp{};
             hp.rows = dv.rows; hp.ld = dv.ld; hp.dim = dv.dim; hp.nd = dv.nd; hp.metric = dv.metric; hp.qp = nullptr; hp.qnorm = nullptr;
             hp.row_of = g->d_row_of; hp.level = g->d_level; hp.n_ids = g->mirror_ids; hp.nbr0 = g->d_nbr0; hp.nbr0_row = g->d_nbr0_row; hp.cnt0 = nullptr;
             hp.stride0 = g->stride0; hp.up_off = g->d_up_off; hp.nbrU = g->d_nbrU; hp.nbrU_row = g->d_nbrU_row; hp.cntU = nullptr; hp.strideU = g->strideU;
             hp.entry_point = (uint32_t)g->ep; hp.max_level = (uint32_t)g->max_level; hp.ef = (uint32_t)g->ef_construction; hp.k = 0;
             hp.out_ids = nullptr; hp.out_dists = nullptr; hp.out_counts = g->d_out_counts; hp.fail = g->d_fail; hp.status = dv.status;
-            hp.qrow = g->d_wq; hp.qlevel = g->d_wq + WALKS;
-            hp.rec_row = g->d_rec_row; hp.rec_d = g->d_rec_d; hp.rec_cnt = g->d_rec_cnt; hp.rec_cap = REC_CAP; hp.rec_zero_mark = vdb_internal::ZERO_NORM_MARK;
-            vdb::launch_hnsw_search(hp, (uint32_t)nc, s);
+            hp.qrow = g->d_wq + (size_t)par * 2 * WALKS; hp.qlevel = hp.qrow + WALKS;
+            hp.rec_row = g->d_rec_row + (size_t)par * WALKS * REC_CAP; hp.rec_d = g->d_rec_d + (size_t)par * WALKS * REC_CAP;
+            hp.rec_cnt = g->d_rec_cnt + (size_t)par * WALKS; hp.rec_cap = REC_CAP; hp.rec_zero_mark = vdb_internal::ZERO_NORM_MARK;
+            vdb::launch_hnsw_search(hp, (uint32_t)nc, sw);
             HN_TRY(hipGetLastError());
             g->stats[1]++;
         }
-        // ---- distances between the chunk's own vectors: pair (i, j), j < i, at tri[i (i - 1) / 2 + j]
-        in_chunk.clear();
-        uint64_t id_lo = ~0ull, id_hi = 0;
-        for (size_t i = 0; i < nc; ++i) {
-            const uint64_t cid = ids ? ids[c0 + i] : first_id + c0 + i;
-            in_chunk[cid] = (uint32_t)i; id_lo = std::min(id_lo, cid); id_hi = std::max(id_hi, cid);
+        HN_TRY(hipEventRecord(g->scan_ev[par], sw));
+        return VDB_OK;
+    };
+    auto clock = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const size_t n_blocks = (n + WALKS - 1) / WALKS;
+    {
+        const auto t0 = clock();
+        if ((rc = sync_mirror(g, s, max_id + 1, up_have + up_need))) return rc;
+        g->btimes[0] += secs(t0, clock());
+        if ((rc = launch_walks(0))) return rc;
+    }
+    for (size_t b = 0; b < n_blocks; ++b) {
+        const size_t c0 = b * WALKS, nc = std::min<size_t>(WALKS, n - c0);
+        const uint32_t par = (uint32_t)(b & 1);
+        const size_t p0 = b ? c0 - WALKS : 0, pn = b ? WALKS : 0;       // the block before this one (of this call)
+        // ---- this block's walks (launched a block ago) are done; the next block's start on the graph as it is now
+        const auto t_block = clock();
+        HN_TRY(hipEventSynchronize(g->scan_ev[par]));
+        const auto t_walked = clock();
+        if (b + 1 < n_blocks) {
+            if ((rc = sync_mirror(g, s, max_id + 1, up_have + up_need))) return rc;
+            if ((rc = launch_walks(b + 1))) return rc;
         }
-        bool dense_ids = id_hi - id_lo + 1 == nc;                     // ids lo .. lo + nc - 1 in order: position = id - lo
-        for (size_t i = 0; i < nc && dense_ids; ++i) dense_ids = (ids ? ids[c0 + i] : first_id + c0 + i) == id_lo + i;
+        const auto t_synced = clock();
+        // ---- the window matrix: this block's vectors against each other (pair (i, j), j < i, at win[i (i - 1) / 2 + j]) and
+        // against the block before (behind the triangle: (i, j) at win[tri_n + i * pn + j]) -- what no walk has seen
+        describe(blk[par], c0, nc);
+        if (b == 0) describe(blk[par ^ 1], 0, 0);
+        const BlockIds& cur = blk[par]; const BlockIds& prev = blk[par ^ 1];
+        const size_t tri_n = nc * (nc - 1) / 2;
         pa.clear(); pb.clear();
         for (size_t i = 1; i < nc; ++i) for (size_t j = 0; j < i; ++j) { pa.push_back(rowv[c0 + i]); pb.push_back(rowv[c0 + j]); }
-        tri.resize(pa.size());
+        for (size_t i = 0; i < nc; ++i) for (size_t j = 0; j < pn; ++j) { pa.push_back(rowv[c0 + i]); pb.push_back(rowv[p0 + j]); }
+        win.resize(pa.size());
         if (!pa.empty()) {
-            if ((rc = vdb_internal::rows_eval(g->flat, pa.data(), pb.data(), pa.size(), tri.data()))) return rc;   // (synchronises the stream: the walks are done too)
+            if ((rc = vdb_internal::rows_eval(g->flat, pa.data(), pb.data(), pa.size(), win.data()))) return rc;
             g->stats[0] += pa.size(); g->stats[1]++; g->bstats[2] += pa.size();
-        } else HN_TRY(hipStreamSynchronize(s));
-        if (have_graph)
+        }
+        const uint32_t* rec_cnt = g->h_rec_cnt + (size_t)par * WALKS;
+        if (walked[par])
             for (size_t i = 0; i < nc; ++i) {
-                g->bstats[1] += std::min<uint32_t>(g->h_rec_cnt[i], REC_CAP);
-                g->stats[0] += std::min<uint32_t>(g->h_rec_cnt[i], REC_CAP);
-                if (g->h_rec_cnt[i] > REC_CAP) g->bstats[5]++;
+                g->bstats[1] += std::min<uint32_t>(rec_cnt[i], REC_CAP);
+                g->stats[0] += std::min<uint32_t>(rec_cnt[i], REC_CAP);
+                if (rec_cnt[i] > REC_CAP) g->bstats[5]++;
             }
         // ---- the authoritative replay, insert by insert
-        const auto t_walked = std::chrono::steady_clock::now();
-        g->btimes[0] += std::chrono::duration<double>(t_synced - t_chunk).count();
-        g->btimes[1] += std::chrono::duration<double>(t_walked - t_synced).count();
+        const auto t_ready = clock();
+        g->btimes[0] += secs(t_walked, t_synced);
+        g->btimes[1] += secs(t_block, t_walked) + secs(t_synced, t_ready);
         struct ReplayClock {
             Graph* g; std::chrono::steady_clock::time_point t0;
             ~ReplayClock() { g->btimes[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
-        } replay_clock{g, t_walked};
+        } replay_clock{g, t_ready};
         for (size_t i = 0; i < nc; ++i) {
-            const uint64_t id = ids ? ids[c0 + i] : first_id + c0 + i;
+            const uint64_t id = id_of(c0 + i);
             const uint32_t my_row = rowv[c0 + i];
             // this insert's record as a hash table node id -> distance (ids, not rows: the replay's inner loop then touches nothing but
             // this table -- a per-distance lookup in the 4 MB id -> row array was a third of its time at 1M nodes)
             std::fill(tab_row.begin(), tab_row.end(), 0xffffffffu);
-            const uint32_t cnt = have_graph ? std::min<uint32_t>(g->h_rec_cnt[i], REC_CAP) : 0u;
-            const uint32_t* rr = g->h_rec_row + (size_t)i * REC_CAP;
-            const float* rd = g->h_rec_d + (size_t)i * REC_CAP;
+            const uint32_t cnt = walked[par] ? std::min<uint32_t>(rec_cnt[i], REC_CAP) : 0u;
+            const uint32_t* rr = g->h_rec_row + ((size_t)par * WALKS + i) * REC_CAP;
+            const float* rd = g->h_rec_d + ((size_t)par * WALKS + i) * REC_CAP;
             for (uint32_t t = 0; t < cnt; ++t) {
                 uint32_t h = (rr[t] * 0x9e3779b1u) >> 17;
                 while (tab_row[h] != 0xffffffffu && tab_row[h] != rr[t]) h = (h + 1) & (TAB - 1);
@@ -942,16 +997,13 @@ int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n
                 fetch_miss_idx.clear();
                 for (size_t t = 0; t < pend.size(); ++t) {
                     const uint64_t nid = pend[t];
-                    if (nid >= id_lo && nid <= id_hi) {                  // a vector of this chunk, inserted before this one?
-                        long cp = -1;
-                        if (dense_ids) cp = (long)(nid - id_lo);
-                        else { auto ic = in_chunk.find(nid); if (ic != in_chunk.end()) cp = (long)ic->second; }
-                        if (cp >= 0) {
-                            const uint32_t a = (uint32_t)i, b = (uint32_t)cp;
-                            d[t] = a > b ? tri[(size_t)a * (a - 1) / 2 + b] : tri[(size_t)b * (b - 1) / 2 + a];
-                            continue;
-                        }
+                    long cp = cur.find(nid);
+                    if (cp >= 0) {                                       // a vector of this block, inserted before this one
+                        const uint32_t a = (uint32_t)i, b2 = (uint32_t)cp;
+                        d[t] = a > b2 ? win[(size_t)a * (a - 1) / 2 + b2] : win[(size_t)b2 * (b2 - 1) / 2 + a];
+                        continue;
                     }
+                    if ((cp = prev.find(nid)) >= 0) { d[t] = win[tri_n + i * pn + (size_t)cp]; continue; }     // of the block before
                     const uint32_t key = (uint32_t)nid;                  // (table key: node ids are below 2^32 - 16)
                     uint32_t h = (key * 0x9e3779b1u) >> 17;
                     while (tab_row[h] != 0xffffffffu && tab_row[h] != key) h = (h + 1) & (TAB - 1);

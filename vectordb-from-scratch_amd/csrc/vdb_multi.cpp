@@ -20,7 +20,9 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
+#include <exception>
 #include <functional>
+#include <stdexcept>
 #include <thread>
 #include <unordered_set>
 
@@ -63,7 +65,7 @@ public:
                     }
                     if (stop_.load(std::memory_order_acquire)) return;
                     seen = epoch_.load(std::memory_order_acquire);
-                    (*job_)(g);
+                    try { (*job_)(g); } catch (...) { threw_.store(true, std::memory_order_release); }   // (re-raised by run() on the caller's thread)
                     if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                         std::lock_guard<std::mutex> lk(mu_);
                         cv_done_.notify_one();
@@ -81,7 +83,10 @@ public:
             }
             cv_go_.notify_all();
         }
-        f(0);
+        // an exception (std::bad_alloc from a message string, say) must not leave run() while workers still execute `f`: it is
+        // held until every shard is done and re-raised here, where the ABI boundary's `guarded` turns it into a status
+        std::exception_ptr ex;
+        try { f(0); } catch (...) { ex = std::current_exception(); }
         if (n_ > 1) {
             const uint64_t t0 = now_ns();
             int it = 0;
@@ -93,6 +98,8 @@ public:
                 }
             }
         }
+        if (ex) std::rethrow_exception(ex);
+        if (threw_.exchange(false)) throw std::runtime_error("internal error: a shard worker raised a C++ exception");
     }
     void stop() {
         {
@@ -112,7 +119,7 @@ private:
     std::condition_variable cv_go_, cv_done_;
     std::atomic<uint64_t> epoch_{0};
     std::atomic<int> remaining_{0};
-    std::atomic<bool> stop_{false};
+    std::atomic<bool> stop_{false}, threw_{false};
     const std::function<void(int)>* job_ = nullptr;
 };
 
