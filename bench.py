@@ -388,6 +388,8 @@ def main():
     def kernel_ms_of(ix, fn, n_iter, rows_local):
         # average duration of ONE launch of the dominant kernel (a batch above the kernel's query tile takes several
         # passes, and the counter sums their launches: stats["filter_launches"])
+        for _ in range(25):                                     # the clock state of a timed region, not of the host work before this call
+            fn()
         ix.set_profile(True)
         ns = []
         for _ in range(n_iter):
@@ -456,24 +458,28 @@ def main():
         for _ in range(3):
             rp.append(one_round(run_pipelined))
             rs.append(one_round(run_sync))
-        pipe_last = tuple(t.clone() for t in bufs[(args.steps - 1) & 1])
-        same = None                                                    # compared with the headline's results below
-        mp_, ms_ = float(np.median(rp)), float(np.median(rs))
-        pipelined = {"value": round(B / (mp_ * 1e-3), 2), "unit": "queries/s", "ms_per_step": round(mp_, 4),
-                     "in_flight": 2, "results_identical_to_synchronous_path": same,
-                     "rounds_ms_per_step": {"pipelined": [round(x, 4) for x in rp], "synchronous_interleaved": [round(x, 4) for x in rs]},
-                     "synchronous_interleaved_ms_per_step": round(ms_, 4),
-                     "note": "vdb_flat_search_batch_device_submit / _wait: batch i+1 is submitted before batch i is waited for; medians of 3 "
-                             "interleaved rounds of --steps batches each (the headline `value` stays the contract's single W + K run)"}
+        # (nothing between the last synchronous round and the headline's W + K steps: tools/clock_series.py shows that 5 ms of an
+        # idle GPU in front of a 5 + 20-step measurement already cost 7 %, 20 ms cost 12 % -- the leg's summary is built afterwards)
+    repeat_rounds = None
+    if world > 1 and not args.lean:
+        # N > 1 has no two-in-flight form: three rounds of the same synchronous group search, reported, in front of the headline
+        repeat_rounds = [round(1e3 * timed(step, 3, args.steps)[0] / max(args.steps, 1), 4) for _ in range(3)]
 
     elapsed, out = timed(step, args.warmup, args.steps)
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     qps = B * args.steps / elapsed
     stats = index.last_stats()
     out = tuple(t.clone() for t in out)          # the search reuses its output tensors; keep this step's results
-    if pipelined is not None:
-        pipelined["results_identical_to_synchronous_path"] = bool(torch.equal(pipe_last[0], out[0]) and
-                                                                  torch.equal(pipe_last[1].view(torch.int32), out[1].view(torch.int32)))
+    if world == 1 and not args.no_pipelined:
+        pipe_last = bufs[(args.steps - 1) & 1]                      # the last pipelined batch's outputs (untouched since)
+        mp_, ms_ = float(np.median(rp)), float(np.median(rs))
+        pipelined = {"value": round(B / (mp_ * 1e-3), 2), "unit": "queries/s", "ms_per_step": round(mp_, 4), "in_flight": 2,
+                     "results_identical_to_synchronous_path": bool(torch.equal(pipe_last[0], out[0]) and
+                                                                   torch.equal(pipe_last[1].view(torch.int32), out[1].view(torch.int32))),
+                     "rounds_ms_per_step": {"pipelined": [round(x, 4) for x in rp], "synchronous_interleaved": [round(x, 4) for x in rs]},
+                     "synchronous_interleaved_ms_per_step": round(ms_, 4),
+                     "note": "vdb_flat_search_batch_device_submit / _wait: batch i+1 is submitted before batch i is waited for; medians of 3 "
+                             "interleaved rounds of --steps batches each (the headline `value` stays the contract's single W + K run)"}
 
     n_prof = max(3, min(args.steps, 10))
     kern_ms = kernel_ms_of(index, step, n_prof, local_rows)
@@ -619,6 +625,17 @@ def main():
         host_io = {"value": round(B * n_io / el, 2), "unit": "queries/s", "ms_per_step": round(1e3 * el / n_io, 4),
                    "note": "host numpy arrays in and out (H2D of the queries, D2H of ids/distances/counts inside the step)"}
 
+    # ---- the same W + K measurement on a GPU that was idle for 20 ms: what a caller sees whose batches do not arrive back to back
+    # (the device drops its clocks within milliseconds of idling and takes longer than W steps to bring them back)
+    after_idle = None
+    if world == 1 and not args.lean:
+        torch.cuda.synchronize()
+        time.sleep(0.02)
+        el_i, _ = timed(step, args.warmup, args.steps)
+        after_idle = {"idle_ms": 20, "ms_per_step": round(1e3 * el_i / max(args.steps, 1), 4), "value": round(B * args.steps / el_i, 2), "unit": "queries/s",
+                      "note": "the headline's W + K steps again, after 20 ms of an idle GPU (the headline itself runs right behind other work); "
+                              "profiles/r03_clock_series.log has the time series"}
+
     # ---- ONE index over all N GPUs inside ONE process (vdb_flat_create_sharded): the object the reference's single server
     # process would hold behind `impl Index`.  Rank 0 builds it over devices 0..N-1 and times the same batch while the other
     # ranks idle on a host-side (gloo) wait -- no kernel of theirs sits on the GPUs.  Bounded: a watchdog thread gives up
@@ -718,7 +735,7 @@ def main():
             "shadow_rows": shadow,
             "f32_exact_tier": f32_tier,
             "gauss_dataset": gauss,
-            "pcie_inclusive": host_io,
+            "pcie_inclusive": host_io, "after_idle": after_idle, "synchronous_rounds_before_headline_ms_per_step": repeat_rounds,
             "single_process_sharded": single,
             "cpu_baseline": cpu,
         }
