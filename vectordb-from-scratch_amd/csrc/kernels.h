@@ -403,6 +403,7 @@ struct HnswSearchParams {
     // rec_zero_mark and ends the walk.
     const uint32_t* qrow; const uint32_t* qlevel;
     uint32_t* rec_row; float* rec_d; uint32_t* rec_cnt; uint32_t rec_cap; uint32_t rec_zero_mark;
+    uint32_t chunk, stage_rows;                                          // set by launch_hnsw_search: staging chunk (elements), rows per staging buffer
 };
 void launch_hnsw_search(const HnswSearchParams& p, uint32_t nq, hipStream_t s);
 // incremental update of the graph mirror: n0 layer-0 records [id, row, level, up_off, ids[stride0], rows[stride0]] and nU

@@ -12,6 +12,7 @@
 // fail[q]; the host re-runs that query with its own traversal.
 #include "kernels.h"
 
+
 #pragma clang fp contract(off)
 
 namespace vdb {
@@ -21,8 +22,8 @@ constexpr uint32_t HT = 256;                  // threads per workgroup
 constexpr uint32_t CAND_CAP = 4096;
 constexpr uint32_t RES_CAP = 1024;            // ef + 1 <= RES_CAP
 constexpr uint32_t VIS_CAP = 16384;           // hash slots; at most 3/4 are used
-constexpr uint32_t CH = 256;                  // row elements per staging chunk
-constexpr uint32_t CHS = CH + 4;              // padded LDS stride of a staged row
+// the rows of an expansion are staged in chunks of `chunk` elements (64..256, chosen on the host so that TWO chunk buffers fit
+// the LDS that the walk's own structures leave: hnsw_stage_plan); a staged row takes chunk + 4 floats
 constexpr uint32_t MAXP = 40;                 // neighbours per expansion at most (m_max0 + 1 <= 40, i.e. m <= 19)
 
 struct HNb { float d; uint32_t id; };
@@ -56,6 +57,8 @@ template <int SIGN> __device__ HNb h_pop(HNb* v, uint32_t& n) {       // n > 0
         uint32_t pos = 0, child = 1;
         HNb e = item;
         item = top;
+        // (tried: two levels per LDS round trip -- the two children and their four children read together; 5 % SLOWER for the
+        // whole walk, like v_pk_* products in the fold: the lane is issue-bound, not latency-bound, once its reads are batched)
         while (end >= 2 && child <= end - 2) {                          // sift_down_to_bottom
             HNb c0 = v[child], c1 = v[child + 1];
             if (h_le<SIGN>(c0, c1)) { ++child; c0 = c1; }
@@ -79,14 +82,16 @@ __global__ __launch_bounds__(HT) void hnsw_search_kernel(HnswSearchParams p) {
     HNb* sCand = reinterpret_cast<HNb*>(sQ + ldq);                                // [CAND_CAP]
     HNb* sRes = sCand + CAND_CAP;                                                 // [RES_CAP]
     uint32_t* sVis = reinterpret_cast<uint32_t*>(sRes + RES_CAP);                 // [VIS_CAP]
-    float* sStage = reinterpret_cast<float*>(sVis + VIS_CAP);                     // [MAXP][CHS]
+    float* sStage = reinterpret_cast<float*>(sVis + VIS_CAP);                     // [2][stage_rows][chunk + 4]
     __shared__ uint32_t sPendId[MAXP], sPendRow[MAXP];
     __shared__ float sPendD[MAXP];
     __shared__ uint32_t sNP, sCont, sCur, sFail, sNVis, sZero, sNCand, sNRes, sRec;
-    __shared__ uint32_t sKeyD[RES_CAP];      // final stable sort: ordered distance
-    __shared__ uint32_t sKeyI[RES_CAP];      //                    position in the heap's backing array
+    // the final stable sort's keys (ordered distance, position in the heap's backing array) live in the staging area, which is
+    // idle by then (>= 8 KB: hnsw_stage_plan)
+    uint32_t* sKeyD = reinterpret_cast<uint32_t*>(sStage);
+    uint32_t* sKeyI = sKeyD + RES_CAP;
 
-    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the query: a prepared query row, or -- insert walks -- a stored row of the index
     const float* qsrc = p.qrow ? p.rows + (size_t)p.qrow[q] * p.ld : p.qp + (size_t)q * p.ld;
     for (uint32_t i = tid; i < ldq; i += HT) sQ[i] = qsrc[i];
@@ -95,47 +100,101 @@ __global__ __launch_bounds__(HT) void hnsw_search_kernel(HnswSearchParams p) {
     const uint32_t ins_level = p.qlevel ? p.qlevel[q] : 0xffffffffu;    // 0xffffffff: a search (ef = 1 above layer 0)
     __syncthreads();
 
-    // distances of sPendRow[0..np) into sPendD, in the reference's operation order
+    // distances of sPendRow[0..np) into sPendD, in the reference's operation order.
+    // The rows come through LDS in chunks, TWO chunks in flight: while lane r folds chunk c of row r (a strictly sequential chain
+    // of adds -- the reference's fold order), the DMA of chunk c + 1 is under way and that of chunk c + 2 is issued as soon as the
+    // fold has freed its buffer.  (One chunk at a time cost a full memory latency per chunk: 3 x 4.4 us of the 25 us an
+    // expansion took at 768 dimensions.)  The DMA is issued from inline asm and waited for with counted s_waitcnt, as in the
+    // filter kernels: hipcc would put a vmcnt(0) in front of every barrier behind the builtin.
+    const uint32_t CHK = p.chunk, CHSK = p.chunk + 4;
+    float* const sBuf0 = sStage;
+    float* const sBuf1 = sStage + (size_t)p.stage_rows * CHSK;
     auto eval_pending = [&](uint32_t np) {
         float s = 0.0f;
         const uint32_t d = p.dim;
-        for (uint32_t c0 = 0; c0 < d; c0 += CH) {
-            const uint32_t cl = d - c0 < CH ? d - c0 : CH;          // elements of this chunk
+        const uint32_t nch = (d + CHK - 1) / CHK;
+        const uint32_t L = wv < np ? (np - wv + 3) / 4 : 0;         // DMA instructions of this wave per chunk (np <= MAXP: at most 10)
+        auto issue = [&](uint32_t c) {
+            const uint32_t c0 = c * CHK;
+            const uint32_t cl = d - c0 < CHK ? d - c0 : CHK;        // elements of this chunk
             const uint32_t nv = (cl + 3) / 4;                       // float4 per row (rows are zero padded up to ld)
-            // one LDS-DMA instruction moves a row's whole chunk (64 lanes x 16 B = 256 elements); every row of the
-            // expansion is in flight at once, the barrier's vmcnt(0) waits for them
-            for (uint32_t r = wv; r < np; r += HT / 64)
+            float* const dst = (c & 1u) ? sBuf1 : sBuf0;
+            // one LDS-DMA instruction moves a row's whole chunk (up to 64 lanes x 16 B); every row of the expansion is in flight at once
+            for (uint32_t r = wv; r < np; r += HT / 64) {
+                const float* gp = p.rows + (size_t)sPendRow[r] * p.ld + c0 + 4 * lane;
+                const uint32_t la = (uint32_t)(uintptr_t)(hn_lds_t)(dst + r * CHSK);
                 if (lane < nv)
-                    __builtin_amdgcn_global_load_lds((hn_glb_t)(p.rows + (size_t)sPendRow[r] * p.ld + c0 + 4 * lane),
-                                                     (hn_lds_t)(sStage + r * CHS), 16, 0, 0);
-            __syncthreads();
-            if (tid < np) {
-                const float* x = sStage + tid * CHS;
-                const float* a = sQ + c0;
-                // 16-byte LDS reads, the adds stay one strictly sequential chain (the reference's fold order)
-                const uint32_t c4 = cl & ~3u;
-                if (p.metric == EUCLID) {
-                    for (uint32_t i = 0; i < c4; i += 4) {
-                        const float4 av = *reinterpret_cast<const float4*>(a + i), xv = *reinterpret_cast<const float4*>(x + i);
-                        float t;
-                        t = __fsub_rn(av.x, xv.x); s = __fadd_rn(s, __fmul_rn(t, t));
-                        t = __fsub_rn(av.y, xv.y); s = __fadd_rn(s, __fmul_rn(t, t));
-                        t = __fsub_rn(av.z, xv.z); s = __fadd_rn(s, __fmul_rn(t, t));
-                        t = __fsub_rn(av.w, xv.w); s = __fadd_rn(s, __fmul_rn(t, t));
-                    }
-                    for (uint32_t i = c4; i < cl; ++i) { float t = __fsub_rn(a[i], x[i]); s = __fadd_rn(s, __fmul_rn(t, t)); }
-                } else {
-                    for (uint32_t i = 0; i < c4; i += 4) {
-                        const float4 av = *reinterpret_cast<const float4*>(a + i), xv = *reinterpret_cast<const float4*>(x + i);
-                        s = __fadd_rn(s, __fmul_rn(av.x, xv.x));
-                        s = __fadd_rn(s, __fmul_rn(av.y, xv.y));
-                        s = __fadd_rn(s, __fmul_rn(av.z, xv.z));
-                        s = __fadd_rn(s, __fmul_rn(av.w, xv.w));
-                    }
-                    for (uint32_t i = c4; i < cl; ++i) s = __fadd_rn(s, __fmul_rn(a[i], x[i]));
-                }
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(la), "v"((const void*)gp) : "memory", "m0");
             }
-            __syncthreads();
+        };
+        auto wait_outstanding = [&](uint32_t n) {                   // s_waitcnt takes an immediate
+            switch (n) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+                case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // nothing older (the previous expansion's record stores) is counted below
+        issue(0);
+        if (nch > 1) issue(1);
+        for (uint32_t c = 0; c < nch; ++c) {
+            const uint32_t c0 = c * CHK;
+            const uint32_t cl = d - c0 < CHK ? d - c0 : CHK;
+            // this wave's pieces of chunk c have landed once only those of chunk c + 1 are outstanding; the barrier says so of every wave
+            wait_outstanding(c + 1 < nch ? L : 0u);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (tid < np) {
+                const float* x = ((c & 1u) ? sBuf1 : sBuf0) + tid * CHSK;
+                const float* a = sQ + c0;
+                // The adds are one strictly sequential chain (the reference's fold order); everything else is kept off it: 16 elements
+                // of both operands are read (eight 16-byte LDS reads in flight together) while the previous 16 are folded -- one
+                // block at a time the lane waited a full LDS latency per four elements, 13 us per expansion at 768 dimensions.
+                const uint32_t c16 = cl & ~15u;
+                float4 av[4], xv[4], an[4], xn[4];
+                if (c16) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { av[u] = *reinterpret_cast<const float4*>(a + 4 * u); xv[u] = *reinterpret_cast<const float4*>(x + 4 * u); }
+                }
+                for (uint32_t i = 0; i < c16; i += 16) {
+                    if (i + 16 < c16) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { an[u] = *reinterpret_cast<const float4*>(a + i + 16 + 4 * u); xn[u] = *reinterpret_cast<const float4*>(x + i + 16 + 4 * u); }
+                    }
+                    if (p.metric == EUCLID) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float t0 = __fsub_rn(av[u].x, xv[u].x), t1 = __fsub_rn(av[u].y, xv[u].y), t2 = __fsub_rn(av[u].z, xv[u].z), t3 = __fsub_rn(av[u].w, xv[u].w);
+                            const float p0 = __fmul_rn(t0, t0), p1 = __fmul_rn(t1, t1), p2 = __fmul_rn(t2, t2), p3 = __fmul_rn(t3, t3);
+                            s = __fadd_rn(s, p0); s = __fadd_rn(s, p1); s = __fadd_rn(s, p2); s = __fadd_rn(s, p3);
+                        }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float p0 = __fmul_rn(av[u].x, xv[u].x), p1 = __fmul_rn(av[u].y, xv[u].y), p2 = __fmul_rn(av[u].z, xv[u].z), p3 = __fmul_rn(av[u].w, xv[u].w);
+                            s = __fadd_rn(s, p0); s = __fadd_rn(s, p1); s = __fadd_rn(s, p2); s = __fadd_rn(s, p3);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { av[u] = an[u]; xv[u] = xn[u]; }
+                }
+                if (p.metric == EUCLID) { for (uint32_t i = c16; i < cl; ++i) { float t = __fsub_rn(a[i], x[i]); s = __fadd_rn(s, __fmul_rn(t, t)); } }
+                else { for (uint32_t i = c16; i < cl; ++i) s = __fadd_rn(s, __fmul_rn(a[i], x[i])); }
+            }
+            // the fold's reads of this buffer are done (their values are consumed): after the barrier it may be refilled
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (c + 2 < nch) issue(c + 2);
         }
         if (tid < np) {
             float dist;
@@ -324,20 +383,39 @@ __global__ __launch_bounds__(64) void hnsw_scatter_kernel(HnswScatterParams p) {
     }
 }
 
-size_t hnsw_search_lds_bytes(uint32_t dim) {
+// Two staging buffers of stage_rows x (chunk + 4) floats in what the walk's own structures leave of the 160 KB: the largest chunk
+// of 256 / 192 / 128 / 64 elements that fits (m = 16 at 768 dimensions: 33 rows x 192), not larger than the rows; 0 = does not fit.
+static uint32_t hnsw_stage_plan(uint32_t dim, uint32_t stage_rows, size_t* bytes) {
     const uint32_t ldq = (dim + 3) & ~3u;
-    return (size_t)ldq * 4 + (size_t)CAND_CAP * 8 + (size_t)RES_CAP * 8 + (size_t)VIS_CAP * 4 + (size_t)MAXP * CHS * 4;
+    const size_t fixed = (size_t)ldq * 4 + (size_t)CAND_CAP * 8 + (size_t)RES_CAP * 8 + (size_t)VIS_CAP * 4;
+    const size_t limit = 160 * 1024 - 1024;                              // (static: the pending lists and a dozen words)
+    if (stage_rows == 0) stage_rows = 1;
+    if (fixed >= limit) return 0;
+    const uint32_t cap = dim <= 64 ? 64u : dim <= 128 ? 128u : dim <= 192 ? 192u : 256u;
+    for (uint32_t chunk : {256u, 192u, 128u, 64u}) {
+        if (chunk > cap) continue;
+        size_t st = (size_t)2 * stage_rows * (chunk + 4) * 4;
+        if (st < (size_t)2 * RES_CAP * 4) st = (size_t)2 * RES_CAP * 4;  // the final sort's keys live there
+        if (fixed + st <= limit) { if (bytes) *bytes = fixed + st; return chunk; }
+    }
+    return 0;
 }
 bool hnsw_search_supported(uint32_t dim, uint32_t ef, uint32_t k, uint32_t max_list) {
-    return (ef > k ? ef : k) + 1 <= RES_CAP && max_list <= MAXP && hnsw_search_lds_bytes(dim) <= 150 * 1024;   // + ~9 KB static
+    return (ef > k ? ef : k) + 1 <= RES_CAP && max_list <= MAXP && hnsw_stage_plan(dim, max_list, nullptr) != 0;
 }
 void launch_hnsw_scatter(const HnswScatterParams& p, hipStream_t s) {
     if (!(p.n0 + p.nU)) return;
     hipLaunchKernelGGL(hnsw_scatter_kernel, dim3(p.n0 + p.nU), dim3(64), 0, s, p);
 }
-void launch_hnsw_search(const HnswSearchParams& p, uint32_t nq, hipStream_t s) {
+void launch_hnsw_search(const HnswSearchParams& p_in, uint32_t nq, hipStream_t s) {
     if (!nq) return;
-    hipLaunchKernelGGL(hnsw_search_kernel, dim3(nq), dim3(HT), hnsw_search_lds_bytes(p.dim), s, p);
+    HnswSearchParams p = p_in;
+    p.stage_rows = std::max(p.stride0, p.strideU);
+    if (p.stage_rows > MAXP) p.stage_rows = MAXP;                        // (the kernel fails such a walk: hnsw_search_supported said no)
+    size_t bytes = 0;
+    p.chunk = hnsw_stage_plan(p.dim, p.stage_rows, &bytes);
+    if (!p.chunk) return;                                                // unsupported shape: the caller checked hnsw_search_supported
+    hipLaunchKernelGGL(hnsw_search_kernel, dim3(nq), dim3(HT), bytes, s, p);
 }
 
 }  // namespace vdb
