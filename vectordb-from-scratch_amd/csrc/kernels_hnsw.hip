@@ -72,6 +72,60 @@ template <int SIGN> __device__ HNb h_pop(HNb* v, uint32_t& n) {       // n > 0
     }
     return item;
 }
+// ---- the same heap operations, executed by a whole WAVE.  A sift is a chain of dependent LDS round trips for a single lane
+// (one per level); here every lane takes one level: the ancestors of a position are known from index arithmetic, so a push reads
+// them all at once, one ballot finds where the element stops, and the shifts are independent writes.  A pop first lets every lane
+// decide one inner node ("which child is larger") -- 64 nodes per ballot --, follows those bits from the root in scalar registers,
+// and then needs one read of the path and one ballot for Rust's sift_down_to_bottom + sift_up pair.  Same comparisons, same
+// final array as the single-lane code above (the order of equal distances depends on it); lane = 0..63, all lanes call.
+__device__ __forceinline__ uint32_t h_anc(uint32_t pos, uint32_t k) { return ((pos + 1u) >> k) - 1u; }   // k-th ancestor of pos
+template <int SIGN> __device__ __forceinline__ void wave_sift_up(HNb* v, uint32_t pos, HNb e, uint32_t lane) {
+    const uint32_t L = 31u - (uint32_t)__builtin_clz(pos + 1u);             // depth of pos: ancestors 1..L
+    bool stop = false;
+    HNb P{0.f, 0u};
+    if (lane >= 1 && lane <= L) { P = v[h_anc(pos, lane)]; stop = h_le<SIGN>(e, P); }
+    const unsigned long long m = __ballot(stop);
+    const uint32_t K = m ? (uint32_t)__builtin_ctzll(m) : L + 1u;           // the first ancestor the element does not pass (L + 1: none)
+    if (lane >= 1 && lane < K) v[h_anc(pos, lane - 1u)] = P;
+    if (lane == 0) v[h_anc(pos, K - 1u)] = e;
+}
+template <int SIGN> __device__ __forceinline__ void wave_push(HNb* v, uint32_t& n, HNb x, uint32_t lane) { wave_sift_up<SIGN>(v, n, x, lane); ++n; }
+constexpr uint32_t WAVE_POP_MAX = 514;                                        // heaps up to this length: 4 ballots of inner nodes
+template <int SIGN> __device__ __forceinline__ void wave_pop_discard(HNb* v, uint32_t& n, uint32_t lane) {   // 0 < n <= WAVE_POP_MAX
+    const HNb e = v[n - 1u];
+    const uint32_t end = --n;
+    if (end == 0) return;
+    // inner nodes with two children: i <= (end - 3) / 2; bit = 1: the right child is taken (h_le(left, right))
+    const uint32_t n2 = end >= 3u ? (end - 3u) / 2u + 1u : 0u;
+    unsigned long long mk[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t i = 64u * r + lane;
+        bool b = false;
+        if (i < n2) { const HNb c0 = v[2u * i + 1u], c1 = v[2u * i + 2u]; b = h_le<SIGN>(c0, c1); }
+        mk[r] = (64u * r < n2) ? __ballot(b) : 0ull;
+    }
+    // the path of sift_down_to_bottom from the root; lane j remembers path[j]
+    uint32_t pos = 0, child = 1, D = 0, mypos = 0;
+    while (end >= 2u && child <= end - 2u) {
+        const unsigned long long mm = pos < 64u ? mk[0] : pos < 128u ? mk[1] : pos < 192u ? mk[2] : mk[3];
+        child += (uint32_t)((mm >> (pos & 63u)) & 1ull);
+        ++D; pos = child;
+        if (lane == D) mypos = pos;
+        child = 2u * pos + 1u;
+    }
+    if (child == end - 1u) { ++D; pos = child; if (lane == D) mypos = pos; }
+    // after the shifts position path[j] holds old[path[j + 1]] and the hole is at path[D]; sift_up from there stops at the deepest j
+    // with e <= old[path[j]]: e lands on path[J], path[0 .. J-1] take old[path[1 .. J]], the rest of the path keeps its values
+    HNb mine{0.f, 0u};
+    bool le_ = false;
+    if (lane >= 1 && lane <= D) { mine = v[mypos]; le_ = h_le<SIGN>(e, mine); }
+    const unsigned long long m = __ballot(le_);
+    const uint32_t J = m ? 63u - (uint32_t)__builtin_clzll(m) : 0u;
+    const uint32_t prev = (uint32_t)__shfl_up((int)mypos, 1);
+    if (lane >= 1 && lane <= J) v[prev] = mine;
+    if (lane == J) v[mypos] = e;
+}
 __device__ __forceinline__ uint32_t vis_hash(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
 }  // namespace
 
@@ -304,20 +358,27 @@ __global__ __launch_bounds__(HT) void hnsw_search_kernel(HnswSearchParams p) {
             const uint32_t np = sNP;
             if (np == 0) continue;
             eval_pending(np);
-            if (tid == 0) {
-                uint32_t nc = sNCand, nr = sNRes;
+            if (wv == 0) {                                                   // one wave folds the new distances into the two heaps
+                uint32_t nc = (uint32_t)__builtin_amdgcn_readfirstlane((int)sNCand), nr = (uint32_t)__builtin_amdgcn_readfirstlane((int)sNRes);
+                // lane i holds neighbour i (np <= 40): the loop below reads them with v_readlane and keeps the furthest result in a
+                // register -- two dependent LDS reads per neighbour, accepted or not, were half of this phase
+                const uint32_t my_d = lane < np ? __float_as_uint(sPendD[lane]) : 0u, my_id = lane < np ? sPendId[lane] : 0u;
+                float furthest = nr ? __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sRes[0].d))) : 3.40282347e+38f;
                 for (uint32_t i = 0; i < np; ++i) {
-                    const float dd = sPendD[i];
-                    const float furthest = nr ? sRes[0].d : 3.40282347e+38f;
+                    const float dd = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)my_d, (int)i));
                     if (dd < furthest || nr < ef) {
-                        if (nc >= CAND_CAP || nr >= RES_CAP) { sFail = 1u; break; }
-                        HNb x{dd, sPendId[i]};
-                        h_push<-1>(sCand, nc, x);
-                        h_push<+1>(sRes, nr, x);
-                        if (nr > ef) (void)h_pop<+1>(sRes, nr);
+                        if (nc >= CAND_CAP || nr >= RES_CAP) { if (lane == 0) sFail = 1u; break; }
+                        const HNb x{dd, (uint32_t)__builtin_amdgcn_readlane((int)my_id, (int)i)};
+                        wave_push<-1>(sCand, nc, x, lane);
+                        wave_push<+1>(sRes, nr, x, lane);
+                        if (nr > ef) {
+                            if (nr <= WAVE_POP_MAX) wave_pop_discard<+1>(sRes, nr, lane);
+                            else { if (lane == 0) (void)h_pop<+1>(sRes, nr); else --nr; }
+                        }
+                        furthest = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sRes[0].d)));
                     }
                 }
-                sNCand = nc; sNRes = nr;
+                if (lane == 0) { sNCand = nc; sNRes = nr; }
             }
             __syncthreads();
         }
