@@ -15,7 +15,7 @@
  * the reference's results; there is no CPU distance path.
  *
  * Inserts are sequential by definition and make no GPU round trip per neighbour expansion.  Bulk inserts evaluate FRONTIERS
- * ONLY: per block of 128 inserts one launch of the device-resident walk (insert mode) evaluates what every insert's
+ * ONLY: per block of 64 inserts one launch of the device-resident walk (insert mode) evaluates what every insert's
  * search_layer asks for and records it -- one block AHEAD of the host, on the graph as of the end of the block before the one
  * being replayed; the host replays the inserts in order with the reference's algorithm, reading distances from the records and
  * asking the GPU again only where the real walk left the speculative one (vdb_hnsw_set_build, vdb_hnsw_build_stats).  Single adds and small batches scan the stored rows ahead of
@@ -81,8 +81,8 @@ int vdb_hnsw_entry_point(const vdb_hnsw_index *h, uint64_t *id, size_t *max_leve
 int vdb_hnsw_stats(const vdb_hnsw_index *h, uint64_t out[6]);
 
 /* How bulk inserts (vdb_hnsw_add_bulk, 32 vectors or more) get their distances.  1 (default): FRONTIER ONLY -- a device walk per
- * insert evaluates what search_layer asks for (graph.rs:155, :182) on the graph as it was 128 + (its position in its block of
- * 128) inserts earlier, while the host replays the block before; the host replays the inserts in order with the reference's
+ * insert evaluates what search_layer asks for (graph.rs:155, :182) on the graph as it was 64 + (its position in its block of
+ * 64) inserts earlier, while the host replays the block before; the host replays the inserts in order with the reference's
  * algorithm and asks the GPU again only where the real walk left the speculative one.  0: the row-scan build (every stored row against every new vector, N^2 / 2 distances).  Same graph either way. */
 int vdb_hnsw_set_build(vdb_hnsw_index *h, int frontier_only);
 /* Counters of the builds since creation: [0] inserts of the frontier-only build, [1] distances its device walks evaluated,

@@ -2,14 +2,15 @@
 // the graph of vdb_hnsw.cpp is mirrored in HBM and ONE workgroup walks it for one query, so a batch needs one launch
 // instead of one launch + host round trip per traversal round.
 //
-// The walk is the reference's, operation by operation.  Thread 0 owns the two priority queues -- Rust's BinaryHeap with
-// the standard library's element moves (neighbor_queue.rs; the backing array decides the order of equal distances in
-// into_sorted_vec) -- in LDS; the neighbour list of the popped candidate is scanned by the lanes of wave 0 (visited set =
-// open-addressing hash in LDS, insertion order restored by a ballot compaction); the distances of the up to 33 unvisited
-// neighbours are evaluated in the reference's exact f32 operation order (distance.rs:37-73): their rows are staged
-// through LDS in chunks of 256 elements by all waves (coalesced), one lane per neighbour folds sequentially and carries
-// its partial sum across chunks.  Anything that does not fit the LDS structures (candidate heap, visited set, ef) sets
-// fail[q]; the host re-runs that query with its own traversal.
+// The walk is the reference's, operation by operation.  The two priority queues -- Rust's BinaryHeap with the standard
+// library's element moves (neighbor_queue.rs; the backing array decides the order of equal distances in into_sorted_vec) --
+// live in LDS; thread 0 pops the next candidate, WAVE 0 pushes an expansion's accepted neighbours (wave_sift_up /
+// wave_pop_discard below: one lane per heap level, a ballot where a single lane would chase LDS latencies); the neighbour list
+// of the popped candidate is scanned by the lanes of wave 0 (visited set = open-addressing hash in LDS, insertion order restored
+// by a ballot compaction); the distances of the up to 33 unvisited neighbours are evaluated in the reference's exact f32
+// operation order (distance.rs:37-73): their rows are staged through LDS in chunks by all waves (LDS-DMA, two chunks in
+// flight), one lane per neighbour folds sequentially and carries its partial sum across chunks.  Anything that does not fit
+// the LDS structures (candidate heap, visited set, ef) sets fail[q]; the host re-runs that query with its own traversal.
 #include "kernels.h"
 
 

@@ -833,12 +833,13 @@ bool walks_supported(const Graph* g) {
 //   the record does not hold is a MISS, evaluated on the GPU at once (one small launch per expansion with misses).
 // The graph is the sequential one by construction -- the replay IS the reference's insert, speculation only decides which
 // distances are already there.  (tests/test_gpu_hnsw.py: node for node equal to the CPU restatement.)
-constexpr uint32_t WALKS = 128, REC_CAP = 12288;          // (the walk's visited set holds 12288 nodes: a longer walk fails anyway)
-// The walks run ONE BLOCK AHEAD of the replay, on their own stream: while the host replays block b (128 inserts, ~25 ms), the GPU
-// walks block b + 1 on the graph as of the end of block b - 1 (~12 ms: a walk is a latency chain, 128 of them occupy 128 CUs and
-// leave the rest to the replay's misses).  The host never waits for a walk launch; the price is that an insert's record is
-// 128 + its position inserts stale instead of its position, i.e. more misses -- distances to the vectors of the block in between
-// come from the window matrix below, like those of the insert's own block.
+constexpr uint32_t WALKS = 64, REC_CAP = 12288;           // (the walk's visited set holds 12288 nodes: a longer walk fails anyway)
+// The walks run ONE BLOCK AHEAD of the replay, on their own stream: while the host replays block b (64 inserts, ~11 ms), the GPU
+// walks block b + 1 on the graph as of the end of block b - 1 (~8 ms: a walk is a latency chain, 64 of them occupy 64 CUs and
+// leave the rest to the replay's misses).  The host never waits for a walk launch; an insert's record is 64 + its position
+// inserts stale -- distances to the vectors of the block in between come from the window matrix below, like those of the insert's
+// own block.  The block is as small as the walk's latency allows: misses fall with the staleness (200k x 768: 2.1 round trips
+// per insert with blocks of 128, 1.1 with 64, 0.83 with 48, where the host starts to wait for the walks).
 
 int build_speculative(Graph* g, const uint64_t* ids, uint64_t first_id, size_t n, const std::vector<uint32_t>& rowv,
                       const std::vector<size_t>& lev, size_t* done) {
