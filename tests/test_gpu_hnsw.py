@@ -197,7 +197,7 @@ def test_recall_floors_of_the_reference(vdb, n, dim, nq, floor):
 def test_frontier_only_build_equals_the_scan_build_and_the_cpu_restatement(vdb, metric):
     """bulk inserts used to fold every new vector against every stored row (N^2 / 2 distances).  The default
     build now runs a device walk per insert that evaluates only what search_layer asks for (graph.rs:155, :182) on the graph as
-    of the start of its chunk of 256, and the host replays the inserts in order -- the SAME graph, node for node, as the
+    of a block of 64 inserts earlier (the walks run one block ahead of the host), and the host replays the inserts in order -- the SAME graph, node for node, as the
     row-scan build and as the CPU restatement; the GPU evaluates a small multiple of the distances the reference's algorithm
     consumes, not N^2 / 2."""
     rng = np.random.default_rng(90 + metric)
