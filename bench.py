@@ -344,9 +344,9 @@ def main():
 
     # ---- the search path: N = 1 the plain device call; N > 1 the C-ABI shard group (RCCL), one process per GPU
     mptr = mask_t.data_ptr() if mask_t is not None else 0
-    group, rccl_ranks = None, None
+    group, rccl_ranks, exchange_note = None, None, None
     if world > 1:
-        # every rank must take the same path: agree on whether the C-ABI group came up everywhere -- and stop if not
+        # every rank must take the same path: agree on whether the C-ABI group came up everywhere
         try:
             group = ShardGroup.from_torch_distributed(local_rank)
             ok, why = 1, ""
@@ -355,9 +355,17 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32, device=device)
         torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            raise SystemExit(f"rank {rank}: the C-ABI shard group (RCCL) could not be created on every rank ({why or 'another rank failed'})")
-        rccl_ranks = group.world()
-        search = group_search(group, index, mask_ptr=mptr, mask_bits=mask_bits)
+            # the library's own RCCL group did not come up on every rank: the same exchange over torch.distributed (three
+            # all-gathers + the HIP merge per batch instead of one collective), and the line says so
+            from vectordb_from_scratch_amd.sharded import torch_group_search
+            group = None
+            exchange_note = ("torch.distributed all_gather_into_tensor x3 + vdb_merge_topk_device (fallback: the C-ABI shard group could "
+                             f"not be created on every rank: {why or 'another rank failed'})")
+            rccl_ranks = world
+            search = torch_group_search(index, mask_ptr=mptr, mask_bits=mask_bits)
+        else:
+            rccl_ranks = group.world()
+            search = group_search(group, index, mask_ptr=mptr, mask_bits=mask_bits)
     else:
         search = gpu_local_search(index, mask_ptr=mptr, mask_bits=mask_bits, reuse_outputs=True)
 
@@ -719,7 +727,7 @@ def main():
             "config": {"workload": cfg["workload"], "name": args.config,
                        "n_rows": n_rows, "rows_per_gpu": local_rows, "dim": dim, "batch": B, "k": k, "distance": mname,
                        "sharding": f"rows/{world}, one process per GPU, exchange = RCCL all-gather + merge behind the C ABI (vdb_flat_search_batch_sharded)"
-                                   if group is not None else "single GPU",
+                                   if group is not None else (f"rows/{world}, one process per GPU, exchange = torch.distributed all-gathers + HIP merge (fallback)" if world > 1 else "single GPU"),
                        "inputs": "queries and outputs resident in HBM",
                        "arithmetic": ("rows, queries and every reported distance are f32 (exact re-rank in the reference's operation "
                                       "order, bit-identical to the f32 oracle); candidates are RANKED by bf16-MFMA scores under an error "
@@ -735,7 +743,7 @@ def main():
             "shadow_rows": shadow,
             "f32_exact_tier": f32_tier,
             "gauss_dataset": gauss,
-            "pcie_inclusive": host_io, "after_idle": after_idle, "synchronous_rounds_before_headline_ms_per_step": repeat_rounds,
+            "pcie_inclusive": host_io, "after_idle": after_idle, "synchronous_rounds_before_headline_ms_per_step": repeat_rounds, "exchange": exchange_note,
             "single_process_sharded": single,
             "cpu_baseline": cpu,
         }

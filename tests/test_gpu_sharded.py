@@ -1,6 +1,8 @@
 """Row shards + the HIP merge kernel on ONE GPU: W independent GpuFlatIndex shards are searched and
 their partial top-k lists merged with vdb_merge_topk_device; the result must equal the unsharded
 index and the oracle bit for bit.  (The collective itself is covered on CPU by test_sharded_cpu.py.)"""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -209,3 +211,39 @@ def test_c_abi_shard_group_single_rank_runs_the_full_rccl_exchange(vdb):
     assert g1.last_stats()["collectives"] == 0
     pi, pdist, _ = ix.search_batch_arrays(q, k)
     assert np.array_equal(gi.astype(np.uint64), pi) and np.array_equal(gd.view(np.uint32), pdist.view(np.uint32))
+
+
+def test_torch_distributed_fallback_exchange_single_rank(vdb):
+    """bench.py's fallback when the library's own RCCL group cannot be created on every rank: the same exchange with
+    torch.distributed as the transport (sharded.torch_group_search).  One rank here: all-gathers over the "nccl" backend (RCCL),
+    the HIP merge, results equal to the plain search; a failing local search raises after the collectives."""
+    import torch
+    import torch.distributed as dist
+    from vectordb_from_scratch_amd.sharded import torch_group_search
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(41)
+        n, d, B, k = 70_000, 64, 19, 7
+        rows = rng.standard_normal((n, d)).astype(np.float32)
+        q = rng.standard_normal((B, d)).astype(np.float32)
+        for metric in (0, 1, 2):
+            ix = vdb.GpuFlatIndex(vdb.DistanceMetric(metric), keep_host_copy=False)
+            ix.add_bulk(rows, first_id=500)
+            gi, gd, gc = (t.cpu().numpy() for t in torch_group_search(ix)(torch.from_numpy(q).cuda(), k))
+            pi, pdist, pc = ix.search_batch_arrays(q, k)
+            assert np.array_equal(gi.astype(np.uint64), pi) and np.array_equal(gd.view(np.uint32), pdist.view(np.uint32)) and np.all(gc == k)
+        ixc = vdb.GpuFlatIndex(vdb.DistanceMetric(1), keep_host_copy=False)
+        ixc.add_bulk(rows)
+        qz = q.copy()
+        qz[3] = 0.0
+        with pytest.raises(vdb.InvalidVector):
+            torch_group_search(ixc)(torch.from_numpy(qz).cuda(), k)
+        gi, _, gc = torch_group_search(ixc)(torch.from_numpy(q).cuda(), k)       # usable afterwards
+        assert int(gc.min()) == k
+    finally:
+        if own:
+            dist.destroy_process_group()

@@ -135,6 +135,46 @@ def merge_topk_hip(ids, dists, counts, k, stream=None):
     return out_i, out_d, out_c
 
 
+def torch_group_search(index, mask_ptr=0, mask_bits=0, group=None):
+    """The same exchange with torch.distributed as the transport: every rank searches its shard, three all-gathers (RCCL under
+    the "nccl" backend) bring the partial top-k lists together, vdb_merge_topk_device merges them on the GPU.  bench.py falls
+    back to this when the C-ABI shard group (include/vdb_shard.h: RCCL called from the library itself) cannot be created on
+    every rank -- it costs three collectives and a blocking local search per batch instead of one collective, and says so in
+    the line.  A rank whose local search fails still takes part in the collectives and raises afterwards; the others raise too."""
+    import torch.distributed as dist
+    local = gpu_local_search(index, mask_ptr=mask_ptr, mask_bits=mask_bits, reuse_outputs=True)
+    cache = {}
+
+    def run(queries, k):
+        B = queries.shape[0]
+        dev = queries.device
+        W = dist.get_world_size(group)
+        key = (B, k, dev)
+        if key not in cache:
+            cache[key] = (torch.empty((W, B, k), dtype=torch.int64, device=dev), torch.empty((W, B, k), dtype=torch.float32, device=dev),
+                          torch.empty((W, B + 1), dtype=torch.int32, device=dev), torch.zeros((B + 1,), dtype=torch.int32, device=dev),
+                          torch.zeros((B, k), dtype=torch.int64, device=dev), torch.zeros((B, k), dtype=torch.float32, device=dev))
+        g_ids, g_d, g_c, mine_c, zero_i, zero_d = cache[key]
+        err = None
+        try:
+            ids, dists, counts = local(queries, k)
+            mine_c[:B] = counts
+            mine_c[B] = 0
+        except Exception as e:                                   # noqa: BLE001 -- re-raised below, after the collectives
+            err, ids, dists = e, zero_i, zero_d
+            mine_c.zero_()
+            mine_c[B] = 1
+        dist.all_gather_into_tensor(g_ids, ids.contiguous(), group=group)
+        dist.all_gather_into_tensor(g_d, dists.contiguous(), group=group)
+        dist.all_gather_into_tensor(g_c, mine_c, group=group)
+        if err is not None:
+            raise err
+        if bool(g_c[:, B].any()):
+            raise IndexError_("a shard on another rank failed the batch")
+        return merge_topk_hip(g_ids, g_d, g_c[:, :B].contiguous(), k)
+    return run
+
+
 def gpu_local_search(index, mask_ptr=0, mask_bits=0, reuse_outputs=False):
     """local_search callable over a GpuFlatIndex with everything resident in HBM.  reuse_outputs=True
     returns the same three output tensors on every call (overwritten by the next search)."""
