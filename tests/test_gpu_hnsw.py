@@ -66,8 +66,11 @@ def test_graph_and_results_equal_the_cpu_restatement(vdb, metric, n, d, m, efc):
     assert_same_results(g, o, queries, 10, 100)
     assert_same_results(g, o, queries[:5], 1, 16)
     assert_same_results(g, o, queries[:5], 200, 50)                     # k > ef: ef_actual = k (graph.rs:406)
+    # the result heap at the edge of what a wave pops with four ballots (514 entries) and beyond it (single-lane pop between wave pushes)
+    assert_same_results(g, o, queries[:4], 10, 513)
+    assert_same_results(g, o, queries[:4], 10, 700)
     st = g.stats()
-    assert st["gpu_distances"] > 0 and st["device_queries"] == 37 + 5 + 5 and st["host_redone"] == 0, st
+    assert st["gpu_distances"] > 0 and st["device_queries"] == 37 + 5 + 5 + 4 + 4 and st["host_redone"] == 0, st
 
 
 def test_device_resident_and_host_traversal_agree(vdb):
