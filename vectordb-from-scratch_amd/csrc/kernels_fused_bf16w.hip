@@ -409,8 +409,10 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
         const uint32_t rowb_ = wr * 64 + (I_) * 32 + 4 * hh_;                                          \
         uint32_t cnt_ = (pcnt_pk[(Q_) >> 1] >> (16 * ((Q_) & 1))) & 0xffffu;                           \
         _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                             \
-            VDB_SCORES(I_, j_, Q_, r01_, r23_)                                                         \
-            VDB_APPEND(I_, j_, r01_.x, r01_.y, r23_.x, r23_.y, thp[Q_], thr_q[Q_], ng[Q_], pool_q, cnt_) \
+            if (hit[Q_][j_] != 0ull) {         /* only the groups of four rows in which some lane has a hit (wave-uniform) */ \
+                VDB_SCORES(I_, j_, Q_, r01_, r23_)                                                     \
+                VDB_APPEND(I_, j_, r01_.x, r01_.y, r23_.x, r23_.y, thp[Q_], thr_q[Q_], ng[Q_], pool_q, cnt_) \
+            }                                                                                          \
         }                                                                                              \
         if (cnt_ > 0xffffu) cnt_ = 0xffffu;                                                            \
         pcnt_pk[(Q_) >> 1] = (pcnt_pk[(Q_) >> 1] & ~(0xffffu << (16 * ((Q_) & 1)))) | (cnt_ << (16 * ((Q_) & 1))); \
@@ -418,7 +420,9 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const uint32_t vbits = (uint32_t)(val >> (32 * i + 4 * h));
-                unsigned long long hit[QT] = {0ull, 0ull, 0ull, 0ull};  // lanes with a possible hit in this row block, per query
+                // lanes with a possible hit, per query and per group of four rows: at k = 100 (config 3) two of three 32 x 32 blocks hold a
+                // hit somewhere, but only one or two of a block's four groups do -- the rare path recomputes just those
+                unsigned long long hit[QT][4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     // scores of 4 rows x 4 queries (two rows per v_pk_fma_f32: the same IEEE fma per element, half the instructions)
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
                         const f32x2 p01 = {acc[i][jq][4 * j + 0], acc[i][jq][4 * j + 1]}, p23 = {acc[i][jq][4 * j + 2], acc[i][jq][4 * j + 3]};
                         const f32x2 r01 = __builtin_elementwise_fma(p01, al01, be01), r23 = __builtin_elementwise_fma(p23, al23, be23);
                         const f32x2 n_ = __builtin_elementwise_min(r01, r23);
-                        hit[jq] |= __builtin_amdgcn_ballot_w64(!(fminf(n_.x, n_.y) > thp[jq]));
+                        hit[jq][j] = __builtin_amdgcn_ballot_w64(!(fminf(n_.x, n_.y) > thp[jq]));
                     }
                     // two groups in flight at a time: with all four the register allocator spills (the kernel sits at 256 VGPRs,
                     // and a scratch access in here costs a vmcnt(0), i.e. a drain of the DMA ring, per tile)
@@ -440,16 +444,16 @@ __global__ __launch_bounds__(NT, 2) void fused_bf16w_kernel(FusedBf16Params p) {
                     asm volatile("" ::: "memory");                      // computing the sums always and selecting with v_cndmask
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        { VDB_SCORES(i, j, 0, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; hit[0] |= __builtin_amdgcn_ballot_w64(t_ != t_); }
-                        { VDB_SCORES(i, j, 1, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; hit[1] |= __builtin_amdgcn_ballot_w64(t_ != t_); }
-                        { VDB_SCORES(i, j, 2, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; hit[2] |= __builtin_amdgcn_ballot_w64(t_ != t_); }
-                        { VDB_SCORES(i, j, 3, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; hit[3] |= __builtin_amdgcn_ballot_w64(t_ != t_); }
+                        { VDB_SCORES(i, j, 0, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; hit[0][j] |= __builtin_amdgcn_ballot_w64(t_ != t_); }
+                        { VDB_SCORES(i, j, 1, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; hit[1][j] |= __builtin_amdgcn_ballot_w64(t_ != t_); }
+                        { VDB_SCORES(i, j, 2, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; hit[2][j] |= __builtin_amdgcn_ballot_w64(t_ != t_); }
+                        { VDB_SCORES(i, j, 3, u01, u23) const f32x2 u_ = u01 + u23; const float t_ = u_.x + u_.y; hit[3][j] |= __builtin_amdgcn_ballot_w64(t_ != t_); }
                     }
                 }
-                if (__builtin_expect(hit[0] != 0ull, 0)) VDB_RARE(i, 0)
-                if (__builtin_expect(hit[1] != 0ull, 0)) VDB_RARE(i, 1)
-                if (__builtin_expect(hit[2] != 0ull, 0)) VDB_RARE(i, 2)
-                if (__builtin_expect(hit[3] != 0ull, 0)) VDB_RARE(i, 3)
+                if (__builtin_expect((hit[0][0] | hit[0][1] | hit[0][2] | hit[0][3]) != 0ull, 0)) VDB_RARE(i, 0)
+                if (__builtin_expect((hit[1][0] | hit[1][1] | hit[1][2] | hit[1][3]) != 0ull, 0)) VDB_RARE(i, 1)
+                if (__builtin_expect((hit[2][0] | hit[2][1] | hit[2][2] | hit[2][3]) != 0ull, 0)) VDB_RARE(i, 2)
+                if (__builtin_expect((hit[3][0] | hit[3][1] | hit[3][2] | hit[3][3]) != 0ull, 0)) VDB_RARE(i, 3)
             }
 #undef VDB_RARE
 #undef VDB_APPEND
