@@ -304,22 +304,25 @@ __global__ __launch_bounds__(HT) void hnsw_search_kernel(HnswSearchParams p) {
         }
         __syncthreads();
         while (true) {
+            // the candidate about to be popped is the top of the heap: it is LOOKED AT first, so that the pop itself (a single lane's
+            // chain through the levels of a heap of a thousand entries) runs in wave 0 beside wave 1's read of that candidate's
+            // neighbour list -- they touch different structures.  (graph.rs:170-176 pops, then compares with the furthest result
+            // and returns: when the walk ends here the heap is not looked at again, so the pop is left out.)
             if (tid == 0) {
-                uint32_t nc = sNCand;
                 uint32_t cont = 0;
-                if (nc && !sFail && !sZero) {
-                    HNb c = h_pop<-1>(sCand, nc);
+                if (sNCand && !sFail && !sZero) {
+                    const HNb c = sCand[0];
                     const float furthest = sNRes ? sRes[0].d : 3.40282347e+38f;
                     if (!(c.d > furthest)) { cont = 1; sCur = c.id; }
                 }
-                sNCand = nc;
                 sCont = cont;
             }
             __syncthreads();
             if (!sCont) break;
+            if (tid == 0) { uint32_t nc = sNCand; (void)h_pop<-1>(sCand, nc); sNCand = nc; }
             // ---- neighbours of sCur at this layer: visited filter, in list order
             const uint32_t cur = sCur;
-            if (wv == 0) {
+            if (wv == 1) {
                 // the whole list in ONE load per lane: lists are padded with 0xffffffff and carry the device row of each
                 // neighbour (0xffffffff = deleted) beside its id, so no count / level / row lookup precedes the distances
                 const uint32_t* lst; const uint32_t* lrow; uint32_t stride;
