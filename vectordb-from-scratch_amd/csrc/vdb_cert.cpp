@@ -80,6 +80,16 @@ Bf16Plan plan_bf16(const vdb_flat_index* ix, uint32_t n, size_t k) {
         const uint32_t kt_pool = round_up((uint32_t)std::max<uint64_t>(16, (6ull * k + per_rank - 1) / per_rank), 16u);
         kt = std::min(kt, kt_pool);
     }
+    // ... and no shallower than four first re-rank rounds (k + 38 rows each) of expected pool: below 250k rows the sample cannot
+    // shrink with the index any more (S = 16384), one sample rank stands for fewer rows, and rank 16 let only ~120 keys per query
+    // through at 125k rows -- 3 in 10000 (query, shard) pairs then ran out of pool before their certificate closed, which at
+    // eight row shards of a 1M-row index sent every second BATCH into the re-threshold pass and a second exchange.  With the
+    // floor (125k rows: rank 32) none in 15000 did, at the same step time.
+    {
+        const double per_rank = (double)n / (double)S;
+        const uint32_t kt_floor = round_up((uint32_t)std::ceil(4.0 * ((double)k + 38.0) / per_rank), 8u);
+        kt = std::min<uint32_t>(std::max(kt, kt_floor), (uint32_t)(S / 256u));
+    }
     if (ix->kn.kt16) kt = std::min<uint32_t>(ix->kn.kt16, (uint32_t)(S / 256u));
     if (kt < 16) return pl;
     pl.kp = k > 48 ? 512 : 256;                                  // candidates the select delivers (depth limit of the re-rank)
