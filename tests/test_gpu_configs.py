@@ -7,6 +7,8 @@
 
 Each is checked through size-independent properties, two whole queries against the CPU oracle (seconds of CPU each) and,
 for C4, the prefix property that ties the device pre-filter to the reference's post-filter (src/storage.rs:268-287)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -161,6 +163,21 @@ def test_c4_1m_x_1536_euclid_with_the_compiled_string_filter(vdb):
     mask2, _ = store.compile_filter(F.And([F.Ne("color", "red"), F.Ne("color", "blue")]))
     hi, _, hc = ix.search_batch_arrays(q_h[:8], k, id_mask=mask2, mask_bits=bits)
     assert np.all(hc == k) and np.all((hi % 4 == 1) | (hi % 4 == 3))
+
+
+def test_c3_full_size_10m_rows_as_eight_shards_of_one_handle(vdb):
+    """BASELINE configs[2] at FULL size: 10M x 768 f32 (30.7 GB of the GPU's 288 GB), dot, batch 1024, k = 100, as ONE
+    vdb_flat_create_sharded handle with 8 row shards on the one GPU of the box -- everything of the 8-GPU job but the wires:
+    rows dealt to the shards, eight local searches of two 512-query passes each, one packed exchange, the merge.  Two queries
+    are compared with the oracle over all 10M rows (ids, order, distance bits)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("c3_full_rehearsal", os.path.join(root, "tools", "c3_full_rehearsal.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if torch.cuda.mem_get_info()[0] < 60 * (1 << 30):
+        pytest.skip("needs 60 GB of free device memory")
+    mod.main()
 
 
 def test_c5_hnsw_at_768_dimensions_against_the_cpu_restatement(vdb):
