@@ -265,6 +265,10 @@ def main():
     ap.add_argument("--data", default="uniform", choices=["uniform", "gauss"], help="distribution of the HEADLINE index")
     ap.add_argument("--screen", type=int, default=1, help="1: bf16 screening tier first (default); 0: f32 MFMA tier only")
     ap.add_argument("--no-wide", action="store_true", help="batches above 256 queries: 256-query passes instead of the 512-query filter kernel (A/B)")
+    ap.add_argument("--rehearse-distributed", action="store_true",
+                    help="one rank, but through every step of the N > 1 code path (process group, C-ABI shard group of one rank, "
+                         "group search, repeat rounds, gloo waits): what the driver's --gpus N run executes, rehearsed on one GPU")
+    ap.add_argument("--rehearse-fallback", action="store_true", help="with the distributed path: behave as if the C-ABI shard group could not be created (the torch.distributed exchange)")
     ap.add_argument("--dry-launch", action="store_true", help="print this rank's RANK / WORLD_SIZE / LOCAL_RANK as a JSON line and exit (no GPU is touched)")
     args = ap.parse_args()
     if args.lean:
@@ -299,9 +303,12 @@ def main():
             raise SystemExit("config c1 is a single-query, single-GPU latency measurement")
         return run_c1(args, vdb, device)
     gloo = None
-    if world > 1:
+    distm = world > 1 or args.rehearse_distributed                # the distributed code path (N > 1, or its one-rank rehearsal)
+    if distm:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(free_port())
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         gloo = dist.new_group(backend="gloo")                       # host-side waits that must not park a kernel on the GPUs
 
@@ -345,9 +352,11 @@ def main():
     # ---- the search path: N = 1 the plain device call; N > 1 the C-ABI shard group (RCCL), one process per GPU
     mptr = mask_t.data_ptr() if mask_t is not None else 0
     group, rccl_ranks, exchange_note = None, None, None
-    if world > 1:
+    if distm:
         # every rank must take the same path: agree on whether the C-ABI group came up everywhere
         try:
+            if args.rehearse_fallback:
+                raise RuntimeError("rehearsal: --rehearse-fallback")
             group = ShardGroup.from_torch_distributed(local_rank)
             ok, why = 1, ""
         except Exception as e:                                   # noqa: BLE001 -- reported, never swallowed
@@ -373,7 +382,7 @@ def main():
         return search(queries if q is None else q, k)
 
     def barrier():
-        if world > 1:
+        if distm:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -386,7 +395,7 @@ def main():
             o = fn()
         barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if distm:
             t = torch.tensor([el], dtype=torch.float64, device=device)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             el = float(t.item())
@@ -432,7 +441,7 @@ def main():
     # driver's 20-step length a single round of either kind moves by several per cent with the clock state the previous
     # leg left behind, and only rounds taken side by side say which form is faster.
     pipelined = None
-    if world == 1 and not args.no_pipelined:
+    if not distm and not args.no_pipelined:
         bufs = [(torch.empty((B, k), dtype=torch.int64, device=device), torch.empty((B, k), dtype=torch.float32, device=device),
                  torch.empty((B,), dtype=torch.int32, device=device)) for _ in range(2)]
 
@@ -469,7 +478,7 @@ def main():
         # (nothing between the last synchronous round and the headline's W + K steps: tools/clock_series.py shows that 5 ms of an
         # idle GPU in front of a 5 + 20-step measurement already cost 7 %, 20 ms cost 12 % -- the leg's summary is built afterwards)
     repeat_rounds = None
-    if world > 1 and not args.lean:
+    if distm and not args.lean:
         # N > 1 has no two-in-flight form: three rounds of the same synchronous group search, reported, in front of the headline
         repeat_rounds = [round(1e3 * timed(step, 3, args.steps)[0] / max(args.steps, 1), 4) for _ in range(3)]
 
@@ -478,7 +487,7 @@ def main():
     qps = B * args.steps / elapsed
     stats = index.last_stats()
     out = tuple(t.clone() for t in out)          # the search reuses its output tensors; keep this step's results
-    if world == 1 and not args.no_pipelined:
+    if not distm and not args.no_pipelined:
         pipe_last = bufs[(args.steps - 1) & 1]                      # the last pipelined batch's outputs (untouched since)
         mp_, ms_ = float(np.median(rp)), float(np.median(rs))
         pipelined = {"value": round(B / (mp_ * 1e-3), 2), "unit": "queries/s", "ms_per_step": round(mp_, 4), "in_flight": 2,
@@ -500,7 +509,7 @@ def main():
     # PMC pass under profiles/ (a line must not carry an older tree's counters)
     traffic, traffic_src = None, None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tp) and world == 1 and args.config == "c2" and n_rows == CONFIGS["c2"]["rows"] and dim == 768:
+    if os.path.exists(tp) and not distm and args.config == "c2" and n_rows == CONFIGS["c2"]["rows"] and dim == 768:
         try:
             tj = json.load(open(tp))
             key = "hbm_bytes_per_launch_bf16_screen" if screened else "hbm_bytes_per_launch"
@@ -558,7 +567,7 @@ def main():
     # ---- opt-in bf16 shadow rows (vdb_flat_set_shadow): +50 % device memory, the filter pass streams 2 bytes per element.
     # Same index, same queries, same results; reported beside the headline (which keeps the f32 rows), never as `value`.
     shadow = None
-    if world == 1 and screened and not args.no_shadow and dim % 64 == 0 and mask_t is None:
+    if not distm and screened and not args.no_shadow and dim % 64 == 0 and mask_t is None:
         index.set_shadow(True)
         els, outs = timed(step, max(3, args.warmup), args.steps)
         sst = index.last_stats()
@@ -584,7 +593,7 @@ def main():
     # each followed by a round on the UNIFORM index in the same clock state (control): the comparison the line makes is
     # between those pairs, not with the headline taken a minute earlier.
     gauss = None
-    if world == 1 and DATA == "uniform" and args.config == "c2" and not args.no_gauss:
+    if not distm and DATA == "uniform" and args.config == "c2" and not args.no_gauss:
         gidx = build_index(vdb, metric, 0, n_rows, n_rows, dim, device, local_rank, data="gauss")
         gq = gen_queries(B, dim, device, data="gauss")
         gsearch = gpu_local_search(gidx, reuse_outputs=True)
@@ -621,7 +630,7 @@ def main():
     # ---- the host-pointer entry point (vdb_flat_search_batch): queries cross PCIe in, results out, per batch.
     # Reported beside the headline, never as `value`.
     host_io = None
-    if world == 1 and not args.no_cpu and mask_t is None:
+    if not distm and not args.no_cpu and mask_t is None:
         q_pin = queries.cpu().numpy()
         for _ in range(3):
             index.search_batch_arrays(q_pin, k)
@@ -636,7 +645,7 @@ def main():
     # ---- the same W + K measurement on a GPU that was idle for 20 ms: what a caller sees whose batches do not arrive back to back
     # (the device drops its clocks within milliseconds of idling and takes longer than W steps to bring them back)
     after_idle = None
-    if world == 1 and not args.lean:
+    if not distm and not args.lean:
         torch.cuda.synchronize()
         time.sleep(0.02)
         el_i, _ = timed(step, args.warmup, args.steps)
@@ -650,7 +659,7 @@ def main():
     # after --single-process-timeout seconds, the line says so, and the headline above is unaffected either way.
     single, leg_hung = None, False
     if not args.no_single_process and args.config in ("c2", "c4") and mask_t is None:
-        if world > 1:
+        if distm:
             torch.distributed.barrier(group=gloo)
         if rank == 0:
             box = {}
@@ -666,7 +675,7 @@ def main():
             th.join(240.0)
             single = box.get("r") or {"error": "timed out after 240 s (the leg was abandoned; the headline is unaffected)"}
             leg_hung = th.is_alive()
-        if world > 1:
+        if distm:
             flag = torch.tensor([1 if leg_hung else 0], dtype=torch.int32)
             torch.distributed.broadcast(flag, src=0, group=gloo)
             leg_hung = bool(flag.item())
@@ -684,7 +693,7 @@ def main():
             live_host = np.unpackbits(mask_t.cpu().numpy().view(np.uint8), bitorder="little")[:n_rows].astype(np.uint8)
         oracle.lib()
         # N = 1: the timed CPU baseline (about cpu-seconds of whole queries); N > 1: two queries, parity only
-        budget = args.cpu_seconds if world == 1 else 0.0
+        budget = args.cpu_seconds if not distm else 0.0
         done, t_cpu, recs, exact = 0, 0.0, [], True
         while done < B and (done < 2 or t_cpu < budget):
             t1 = time.perf_counter()
@@ -694,7 +703,7 @@ def main():
             exact &= bool(np.array_equal(oi, ids_g[done, :len(oi)]) and np.array_equal(od, dist_g[done, :len(od)]))
             done += 1
         recall = float(np.mean(recs))
-        if world == 1:
+        if not distm:
             cpu = {"value": round(done / t_cpu, 4), "unit": "queries/s", "cores": 1, "kind": "port",
                    "sample": f"{done} of {B} queries against all {n_rows} rows, {t_cpu:.1f} s; oracle/flat_oracle.c "
                              f"(C restatement of the reference's single-threaded FlatIndex::search; the Rust reference "
@@ -727,7 +736,7 @@ def main():
             "config": {"workload": cfg["workload"], "name": args.config,
                        "n_rows": n_rows, "rows_per_gpu": local_rows, "dim": dim, "batch": B, "k": k, "distance": mname,
                        "sharding": f"rows/{world}, one process per GPU, exchange = RCCL all-gather + merge behind the C ABI (vdb_flat_search_batch_sharded)"
-                                   if group is not None else (f"rows/{world}, one process per GPU, exchange = torch.distributed all-gathers + HIP merge (fallback)" if world > 1 else "single GPU"),
+                                   if group is not None else (f"rows/{world}, one process per GPU, exchange = torch.distributed all-gathers + HIP merge (fallback)" if distm else "single GPU"),
                        "inputs": "queries and outputs resident in HBM",
                        "arithmetic": ("rows, queries and every reported distance are f32 (exact re-rank in the reference's operation "
                                       "order, bit-identical to the f32 oracle); candidates are RANKED by bf16-MFMA scores under an error "
@@ -752,14 +761,14 @@ def main():
         if parity_n is not None:
             line["parity"] = parity_n
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distm:
         torch.distributed.barrier(group=gloo)
     if leg_hung:
         # an abandoned single-process leg still holds a thread inside the library: no teardown, no interpreter shutdown -- the
         # line is out and the ranks are in step, so every rank leaves at once
         sys.stdout.flush()
         os._exit(0)
-    if world > 1:
+    if distm:
         del group
         torch.distributed.destroy_process_group()
 
