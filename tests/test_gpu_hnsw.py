@@ -215,6 +215,8 @@ def test_frontier_only_build_equals_the_scan_build_and_the_cpu_restatement(vdb, 
     assert bs["reference_distances"] > 0 and gpu <= 3 * bs["reference_distances"], bs     # within 3x of what the algorithm evaluates
     assert gpu < n * (n - 1) // 2, bs                                                   # (the row scans' count; at 6000 nodes a walk still sees a sixth of the graph)
     assert bs["record_overflows"] == 0, bs
+    bt = g.build_times()                                               # vdb_hnsw_build_times: where the build's wall time went
+    assert bt["replay_s"] > 0 and bt["replay_s"] >= bt["replay_miss_round_trips_s"] >= 0 and bt["walks_s"] >= 0 and bt["mirror_sync_s"] >= 0, bt
     g2 = vdb.GpuHnswIndex(vdb.DistanceMetric(metric), vdb.HnswParams.new(m, efc, 50), seed=11 + metric)
     g2.set_build(False)                                                # the row-scan build of round 2
     g2.build_batch((ids, rows))
